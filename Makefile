@@ -1,0 +1,31 @@
+# Builds the three in-tree shared libraries:
+#   clraytracer_amd/csrc/libcrt_hip.so   HIP kernels + C-ABI (include/crt_api.h), gfx950 only
+#   clraytracer_amd/host/libcrt_host.so  C++ host mirror of Renderer/ResourceManager/AssetManager (+ include/crt_host.h)
+#   oracle/libcrt_oracle.so              CPU oracle (test infrastructure only)
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+CXXFLAGS = -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -pthread
+
+HIP_SO = clraytracer_amd/csrc/libcrt_hip.so
+HOST_SO = clraytracer_amd/host/libcrt_host.so
+HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp)
+HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
+
+all: $(HIP_SO) $(HOST_SO) oracle
+
+$(HIP_SO): clraytracer_amd/csrc/crt_shim.hip clraytracer_amd/csrc/crt_device.h include/crt_api.h include/crt_types.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ clraytracer_amd/csrc/crt_shim.hip
+
+$(HOST_SO): $(HOST_SRC) $(HOST_HDR) $(HIP_SO)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -Lclraytracer_amd/csrc -lcrt_hip -Wl,-rpath,'$$ORIGIN/../csrc'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(HIP_SO) $(HOST_SO)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,338 @@
+// crt_device.h -- device-side data layout and the per-ray traversal/shading code (gfx950).
+//
+// Reference semantics restated for CDNA4 (citations relative to upstream CLRayTracer/...):
+//   kernels/kernel_main.cl:84-160   IntersectTriangle / IntersectAABB / IntersectBVH
+//   kernels/kernel_main.cl:164-275  Trace          kernels/kernel_main.cl:277-287  RayGen
+//   kernels/MathAndSTL.cl:100-119, 243-266  MatMul / Mat3Mul / reflect / colour / sampling
+// Arithmetic contract (must match oracle/crt_oracle.h "Pinned builtin semantics"): fp32, no FMA
+// contraction (-ffp-contract=off), IEEE divide/sqrt, per-ray operation order exactly upstream's.
+//
+// HBM layout (built by the relayout kernels in crt_shim.hip from the reference-layout uploads):
+//   pairs   : one 64-byte, 64-byte-aligned record per sibling pair {L.min,L.ref | L.max,- |
+//             R.min,R.ref | R.max,-}; pair index = leftFirst >> 1 (siblings are adjacent upstream,
+//             BVH.cpp:203-204). One inner-node visit = one aligned 64-byte fetch per lane.
+//   ref     : 32-bit child descriptor. Inner: pair index. Leaf: bit31 | count<<24 | firstTri
+//             (count 1..127; 0 = look up CrtDevScene::bigLeaf[firstTri]). A popped/descended node
+//             needs no re-fetch to learn whether it is a leaf (upstream re-reads the 32-byte node).
+//   triHot  : 36 bytes per triangle {v0, v1-v0, v2-v0} (edges precomputed with the same fp32
+//             subtraction upstream performs per test -> bit-identical), read only by leaf tests.
+//   triCold : the 32-byte attribute tail of the reference Tri (uv halfs, material, normal halfs),
+//             read once per shaded hit.
+//   texels  : RGBA8 (one dword per texel) expanded from the packed RGB8 pool.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/crt_types.h"
+
+#define CRT_LEAF_BIT 0x80000000u
+#define CRT_BLOCK 256
+#define CRT_TILE 16
+
+struct CrtDevScene {
+    const float4* __restrict__ pairs;
+    const float* __restrict__ triHot;
+    const uint4* __restrict__ triCold;
+    const uint32_t* __restrict__ bigLeaf;
+    const uint32_t* __restrict__ rootRefs;
+    const CrtMeshInstance* __restrict__ instances;
+    const CrtMaterial* __restrict__ materials;
+    const CrtTexture* __restrict__ textures;
+    const uint32_t* __restrict__ texels;
+    int numTexels;
+    uint32_t numInstances;
+};
+
+struct CrtFrame {
+    float invView[16];
+    float invProj[16];
+    float camPos[3];
+    float lightY, lightZ;     // (float)sin((double)sunAngle), (float)cos((double)sunAngle), computed on the host
+    int width, height;
+    int tilesX;               // ceil(width / 16)
+    int numTiles;             // tilesX * owned tile rows
+    int chunk;                // ceil(numTiles / 8): tiles per XCD slab
+    int tileRowsPerBand;      // bandRows / 16
+    int rank, nRanks;
+};
+
+struct v3 { float x, y, z; };
+
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ v3 add3(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 sub3(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 mul3(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 scale3(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 neg3(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ v3 cross3(v3 a, v3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ v3 normalize3(v3 v)
+{
+    float inv = 1.0f / sqrtf(dot3(v, v));
+    return scale3(v, inv);
+}
+__device__ __forceinline__ v3 reflect3(v3 v, v3 n)
+{
+    float d = dot3(n, v);
+    return sub3(v, scale3(scale3(n, d), 2.0f));
+}
+// (int) pinned: truncation, NaN -> 0, saturating
+__device__ __forceinline__ int f2i(float x)
+{
+    if (!(x == x)) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)x;
+}
+__device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__ushort_as_half((unsigned short)bits16)); }
+
+struct Triout { float t, u, v; uint32_t tri; };
+
+struct LaneCounters {
+    uint32_t rays, primary, secondary, hits, misses;
+    uint32_t traversals, pops, innerVisits, triTests, capHits, stackOverflows, maxStack;
+};
+
+// kernel_main.cl:108-117
+__device__ __forceinline__ float intersect_aabb(v3 o, v3 inv, float4 bmin, float4 bmax, float minSoFar)
+{
+    float tminx = (bmin.x - o.x) * inv.x, tminy = (bmin.y - o.y) * inv.y, tminz = (bmin.z - o.z) * inv.z;
+    float tmaxx = (bmax.x - o.x) * inv.x, tmaxy = (bmax.y - o.y) * inv.y, tmaxz = (bmax.z - o.z) * inv.z;
+    float tnear = fmaxf(fmaxf(fminf(tminx, tmaxx), fminf(tminy, tmaxy)), fminf(tminz, tmaxz));
+    float tfar  = fminf(fminf(fmaxf(tminx, tmaxx), fmaxf(tminy, tmaxy)), fmaxf(tminz, tmaxz));
+    return (tnear < tfar && tnear > 0.0f && tnear < minSoFar) ? tnear : 1e30f;
+}
+
+// kernel_main.cl:84-106; hot = {v0, edge1, edge2}
+__device__ __forceinline__ int intersect_triangle(v3 o, v3 d, const float* __restrict__ hot, Triout& out, uint32_t i)
+{
+    const v3 x = mk3(hot[0], hot[1], hot[2]);
+    const v3 edge1 = mk3(hot[3], hot[4], hot[5]);
+    const v3 edge2 = mk3(hot[6], hot[7], hot[8]);
+    const v3 h = cross3(d, edge2);
+    const float a = dot3(edge1, h);
+    const float f = 1.0f / a;
+    const v3 s = sub3(o, x);
+    const float u = f * dot3(s, h);
+    const v3 q = cross3(s, edge1);
+    const float v = f * dot3(d, q);
+    const float t = f * dot3(edge2, q);
+    int passed = (((int)(t > 0.0f) ^ (int)(t < out.t)) + (int)(u < 0.0f) + (int)(u > 1.0f) + (int)(v < 0.0f) + (int)(u + v > 1.0f)) == 0;
+    int notPassed = 1 - passed;
+    // arithmetic blend kept as upstream (NaN/inf propagate through the 0-weighted term)
+    out.u = u * (float)passed + ((float)notPassed * out.u);
+    out.v = v * (float)passed + ((float)notPassed * out.v);
+    out.t = t * (float)passed + ((float)notPassed * out.t);
+    out.tri = i * (uint32_t)passed + ((uint32_t)notPassed * out.tri);
+    return passed;
+}
+
+// kernel_main.cl:124-160. `stack` points at this lane's column of the workgroup's LDS stack
+// (slot s lives at stack[s * CRT_BLOCK]): 32 slots x 4 B x 64 lanes = 8 KiB per wave, bank-conflict
+// free because consecutive lanes hit consecutive dwords.
+template <bool COUNT>
+__device__ __forceinline__ int intersect_bvh(const CrtDevScene& S, v3 o, v3 d, uint32_t rootRef, Triout& out,
+                                             uint32_t* stack, LaneCounters& lc)
+{
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 1, protection = 0, intersection = 0;
+    stack[0] = rootRef;
+    if (COUNT) lc.traversals++;
+
+    while (sp > 0) {
+        if (!(protection++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; break; }
+        if (COUNT) lc.pops++;
+        --sp;
+        uint32_t ref = stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK];
+        for (;;) {
+            if (ref & CRT_LEAF_BIT) {
+                uint32_t first = ref & 0x00FFFFFFu;
+                uint32_t cnt = (ref >> 24) & 0x7Fu;
+                if (cnt == 0) cnt = S.bigLeaf[first];
+                for (uint32_t i = first, end = first + cnt; i < end; ++i) {
+                    if (COUNT) lc.triTests++;
+                    intersection |= intersect_triangle(o, d, S.triHot + (size_t)i * 9, out, i);
+                }
+                break;
+            }
+            const float4* p = S.pairs + (size_t)ref * 4;
+            const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+            if (COUNT) lc.innerVisits++;
+            float dist1 = intersect_aabb(o, inv, lmin, lmax, out.t);
+            float dist2 = intersect_aabb(o, inv, rmin, rmax, out.t);
+            uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
+            if (dist1 > dist2) {
+                float tf = dist1; dist1 = dist2; dist2 = tf;
+                uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
+            }
+            if (dist1 == 1e30f) break;
+            ref = nearRef;
+            if (dist2 != 1e30f) {
+                if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
+                stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] = farRef;
+                sp++;
+                if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
+            }
+        }
+    }
+    return intersection;
+}
+
+// MathAndSTL.cl:100-102 with a row-major matrix in memory: ((m.x*v.x + m.y*v.y) + m.z*v.z) + m.w*v.w
+__device__ __forceinline__ v3 matmul_xyz(const float* __restrict__ m, float vx, float vy, float vz, float vw)
+{
+    v3 r;
+    r.x = ((m[0] * vx + m[4] * vy) + m[8] * vz) + m[12] * vw;
+    r.y = ((m[1] * vx + m[5] * vy) + m[9] * vz) + m[13] * vw;
+    r.z = ((m[2] * vx + m[6] * vy) + m[10] * vz) + m[14] * vw;
+    return r;
+}
+__device__ __forceinline__ float matmul_w(const float* __restrict__ m, float vx, float vy, float vz, float vw)
+{
+    return ((m[3] * vx + m[7] * vy) + m[11] * vz) + m[15] * vw;
+}
+__device__ __forceinline__ v3 mat3mul(const float* __restrict__ m, v3 v)
+{
+    v3 r;
+    r.x = (m[0] * v.x + m[4] * v.y) + m[8] * v.z;
+    r.y = (m[1] * v.x + m[5] * v.y) + m[9] * v.z;
+    r.z = (m[2] * v.x + m[6] * v.y) + m[10] * v.z;
+    return r;
+}
+
+struct Closest { float distance; int hitInstance; int anyHit; Triout hit; };
+
+// kernel_main.cl:198-217: every ray visits every instance (there is no TLAS upstream).
+template <bool COUNT>
+__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, uint32_t* stack, LaneCounters& lc)
+{
+    Closest c;
+    c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
+    c.hit.t = 0.0f; c.hit.u = 0.0f; c.hit.v = 0.0f; c.hit.tri = 0;
+    for (uint32_t i = 0; i < S.numInstances; ++i) {
+        Triout triout;
+        triout.t = c.distance; triout.tri = 0; triout.u = 0.0f; triout.v = 0.0f;
+        const CrtMeshInstance* inst = S.instances + i;       // uniform index -> scalar loads
+        const float* m = &inst->inverseTransform.m[0][0];
+        v3 mo = matmul_xyz(m, o.x, o.y, o.z, 1.0f);
+        v3 md = matmul_xyz(m, d.x, d.y, d.z, 0.0f);
+        uint32_t rootRef = S.rootRefs[inst->meshIndex];
+        if (intersect_bvh<COUNT>(S, mo, md, rootRef, triout, stack, lc)) {
+            c.hitInstance = (int)i;
+            c.hit = triout;
+            c.distance = triout.t;
+            c.anyHit = 1;
+        }
+    }
+    return c;
+}
+
+__device__ __forceinline__ int clamp_texel(int idx, int n) { return idx < 0 ? 0 : (idx >= n ? n - 1 : idx); }
+
+// MathAndSTL.cl:253-258 (hard-wired to textures[2] and pool offset 2 upstream, hazard H9)
+__device__ __forceinline__ int sample_skybox(v3 d, int texW, int texH)
+{
+    const double PI = 3.14159265358979323846;
+    float at = (float)(atan2((double)d.x, (double)(-d.z)) / PI);
+    float ac = (float)(acos((double)d.y) / PI);
+    int theta = f2i((at * 0.5f) * (float)texW);
+    int phi = f2i(ac * (float)texH);
+    return (int)((uint32_t)phi * (uint32_t)texW + (uint32_t)(theta + 2));
+}
+
+// MathAndSTL.cl:260-266
+__device__ __forceinline__ int sample_texture(const CrtTexture& tex, float u, float v)
+{
+    u = u - floorf(u);
+    v = v - floorf(v);
+    int uS = f2i((float)tex.width * u);
+    int vS = f2i((float)tex.height * v);
+    return (int)((uint32_t)vS * (uint32_t)tex.width + (uint32_t)tex.offset + (uint32_t)uS);
+}
+
+// kernel_main.cl:277-287
+__device__ __forceinline__ v3 raygen_dir(const CrtFrame& F, int i, int j)
+{
+    float cx = (float)i / (float)F.width, cy = (float)j / (float)F.height;
+    cx = cx * 2.0f - 1.0f;
+    cy = cy * 2.0f - 1.0f;
+    v3 t = matmul_xyz(F.invProj, cx, cy, 1.0f, 1.0f);
+    float w = matmul_w(F.invProj, cx, cy, 1.0f, 1.0f);
+    float tx = t.x / w, ty = t.y / w, tz = t.z / w, tw = w / w;
+    v3 wv = matmul_xyz(F.invView, tx, ty, tz, tw);
+    return normalize3(wv);
+}
+
+// One bounce of kernel_main.cl:187-272 after the closest hit is known. Returns false when the
+// path terminated (miss -> skybox). On a hit, updates ray/energy/atmospheric/lightDir in place.
+struct PathState { v3 o, d, result, energy, atm, light; };
+
+__device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest& c, PathState& ps)
+{
+    const float UcharToFloat01 = 1.0f / 255.0f;
+    if (c.distance > 99998.0f) {
+        const CrtTexture sky = S.textures[2];
+        int idx = clamp_texel(sample_skybox(ps.d, sky.width, sky.height), S.numTexels);
+        uint32_t px = S.texels[idx];
+        v3 skyc = scale3(mk3((float)(px & 0xffu), (float)((px >> 8) & 0xffu), (float)((px >> 16) & 0xffu)), UcharToFloat01);
+        ps.result = add3(ps.result, mul3(skyc, ps.energy));
+        return false;
+    }
+    const CrtMeshInstance* inst = S.instances + c.hitInstance;
+    const float* m = &inst->inverseTransform.m[0][0];
+    // meshRay of the winning instance, recomputed with the same arithmetic as in the loop
+    const v3 mo = matmul_xyz(m, ps.o.x, ps.o.y, ps.o.z, 1.0f);
+    const v3 md = matmul_xyz(m, ps.d.x, ps.d.y, ps.d.z, 0.0f);
+
+    const uint4 c0 = S.triCold[(size_t)c.hit.tri * 2], c1 = S.triCold[(size_t)c.hit.tri * 2 + 1];
+    // c0 = {uv0x|uv0y, uv1x|uv1y, uv2x|uv2y, mat|n0x}; c1 = {n0y|n0z, n1x|n1y, n1z|n2x, n2y|n2z}
+    const uint32_t matIndex = c0.w & 0xffffu;
+    uint32_t mi = (uint32_t)inst->materialStart + matIndex;
+    mi = mi < (uint32_t)CRT_MAX_MATERIALS ? mi : (uint32_t)CRT_MAX_MATERIALS - 1;
+    const CrtMaterial mat = S.materials[mi];
+    const float bx = (1.0f - c.hit.u) - c.hit.v, by = c.hit.u, bz = c.hit.v;
+
+    const v3 n0 = mat3mul(m, mk3(h2f(c0.w >> 16), h2f(c1.x & 0xffffu), h2f(c1.x >> 16)));
+    const v3 n1 = mat3mul(m, mk3(h2f(c1.y & 0xffffu), h2f(c1.y >> 16), h2f(c1.z & 0xffffu)));
+    const v3 n2 = mat3mul(m, mk3(h2f(c1.z >> 16), h2f(c1.w & 0xffffu), h2f(c1.w >> 16)));
+    const v3 normal = normalize3(add3(add3(scale3(n0, bx), scale3(n1, by)), scale3(n2, bz)));
+
+    const float uvx = (h2f(c0.x & 0xffffu) * bx + h2f(c0.y & 0xffffu) * by) + h2f(c0.z & 0xffffu) * bz;
+    const float uvy = (h2f(c0.x >> 16) * bx + h2f(c0.y >> 16) * by) + h2f(c0.z >> 16) * bz;
+
+    uint32_t ti = mat.albedoTextureIndex;
+    ti = ti < (uint32_t)CRT_MAX_TEXTURES ? ti : (uint32_t)CRT_MAX_TEXTURES - 1;
+    const CrtTexture tex = S.textures[ti];
+    const uint32_t px = S.texels[clamp_texel(sample_texture(tex, uvx, uvy), S.numTexels)];
+    // the specular texel (kernel_main.cl:243) is fetched upstream but never used: not fetched here
+    const uint32_t a = mat.color;
+    const uint32_t cr = (((a & 0xffu) * (px & 0xffu)) >> 8) & 0xffu;
+    const uint32_t cg = ((((a >> 8) & 0xffu) * ((px >> 8) & 0xffu)) >> 8) & 0xffu;
+    const uint32_t cb = ((((a >> 16) & 0xffu) * ((px >> 16) & 0xffu)) >> 8) & 0xffu;
+    const v3 color = scale3(mk3((float)cr, (float)cg, (float)cb), UcharToFloat01);
+    const v3 point = add3(mo, scale3(md, c.hit.t));
+
+    const v3 specularColor = mk3(0.2f, 0.2f, 0.2f);
+    const float roughness = 0.5f;
+    const float shadow = 1.0f;
+
+    ps.o = add3(point, scale3(normal, 0.01f));
+    ps.d = reflect3(ps.d, normal);
+
+    float ndl = dot3(normal, neg3(ps.light));
+    const v3 ambient = mul3(scale3(ps.atm, fmaxf(0.0f - ndl, 0.1f)), color);
+    ndl = fmaxf(ndl, 0.0f);
+    const float sp = ((1.0f - roughness) * ndl) * shadow;
+    const v3 specular = scale3(mul3(mk3(sp, sp, sp), specularColor), ndl);
+    // pow(x, shininess) with shininess == 1.0f (kernel_main.cl:250) is exactly x
+    const float sl = (ndl * fmaxf(dot3(reflect3(neg3(ps.light), normal), md), 0.0f)) * 0.2f;
+
+    ps.result = add3(ps.result, add3(add3(mul3(ps.energy, scale3(color, ndl)), ambient), mk3(sl, sl, sl)));
+    ps.energy = mul3(ps.energy, specular);
+    ps.atm = scale3(ps.atm, 0.4f);
+    ps.light = ps.d;
+    return true;
+}

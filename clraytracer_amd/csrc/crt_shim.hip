@@ -1,0 +1,678 @@
+// crt_shim.hip -- kernels and the C-ABI (include/crt_api.h) of the MI355X ray-trace path.
+//
+// Replaces the OpenCL side of the reference's Renderer.cpp / ResourceManager.cpp: device pools,
+// uploads, the per-frame RayGen -> Trace -> PostProcess launch (Renderer.cpp:305-375). Uploads
+// arrive in the reference's struct layouts and are re-laid-out on the device (crt_device.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/crt_api.h"
+#include "crt_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
+__device__ __forceinline__ void flush_counters(const LaneCounters& lc, unsigned long long* g)
+{
+    // every lane of the wave must call this (inactive pixels contribute zeros)
+    uint32_t s[11] = { lc.rays, lc.primary, lc.secondary, lc.hits, lc.misses, lc.traversals, lc.pops,
+                       lc.innerVisits, lc.triTests, lc.capHits, lc.stackOverflows };
+    uint32_t mx = wave_max(lc.maxStack);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        uint32_t t = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(&g[k], (unsigned long long)t);
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&g[11], (unsigned long long)mx);
+}
+
+__device__ __forceinline__ void zero_counters(LaneCounters& lc)
+{
+    lc.rays = lc.primary = lc.secondary = lc.hits = lc.misses = 0;
+    lc.traversals = lc.pops = lc.innerVisits = lc.triTests = lc.capHits = lc.stackOverflows = lc.maxStack = 0;
+}
+
+// Pixel of this lane. A 256-thread workgroup owns a 16x16 tile; each wave64 an 8x8 sub-tile in
+// Morton order (coherent ray packets). Workgroups are dealt round-robin over the 8 XCDs, so
+// linear block id b -> tile (b % 8) * chunk + b / 8 gives every XCD (own L2) one contiguous
+// slab of the frame.
+__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py)
+{
+    const int b = blockIdx.x;
+    const int t = (b & 7) * F.chunk + (b >> 3);
+    if (t >= F.numTiles) return false;
+    const int k = t / F.tilesX, tx = t - k * F.tilesX;
+    const int bandK = k / F.tileRowsPerBand;
+    const int tileRow = (F.rank + bandK * F.nRanks) * F.tileRowsPerBand + (k - bandK * F.tileRowsPerBand);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
+    const int ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    px = tx * CRT_TILE + (wave & 1) * 8 + lx;
+    py = tileRow * CRT_TILE + (wave >> 1) * 8 + ly;
+    return px < F.width && py < F.height;
+}
+
+// kernel Trace (kernel_main.cl:164-275) with RayGen (kernel_main.cl:277-287) fused: the ray
+// direction is computed with the same arithmetic RayGen stores, so the 24.9 MB ray buffer
+// round-trip disappears. One thread per pixel, both bounces.
+template <bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+                                                              unsigned long long* __restrict__ counters)
+{
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    uint32_t* stack = s_stack + threadIdx.x;
+    LaneCounters lc; zero_counters(lc);
+    int px, py;
+    const bool active = lane_pixel(F, px, py);
+    if (active) {
+        PathState ps;
+        ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
+        ps.d = raygen_dir(F, px, py);
+        ps.light = mk3(0.0f, F.lightY, F.lightZ);
+        ps.result = mk3(0.0f, 0.0f, 0.0f);
+        ps.energy = mk3(1.0f, 1.0f, 1.0f);
+        ps.atm = scale3(mk3(0.255f, 0.25f, 0.27f), 1.0f);
+        for (int bounce = 0; bounce < 2; ++bounce) {
+            if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
+            Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
+            bool cont = shade_bounce(S, c, ps);
+            if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
+            if (!cont) break;
+        }
+        out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    if (COUNT) flush_counters(lc, counters);
+}
+
+// kernel RayGen as its own launch (only for CRT_RENDER_WRITE_RAYS)
+__global__ __launch_bounds__(CRT_BLOCK) void crt_raygen_kernel(CrtFrame F, float* __restrict__ rays)
+{
+    int px, py;
+    if (!lane_pixel(F, px, py)) return;
+    v3 d = raygen_dir(F, px, py);
+    float* o = rays + 3 * ((size_t)px + (size_t)py * (size_t)F.width);
+    o[0] = d.x; o[1] = d.y; o[2] = d.z;
+}
+
+// kernel PostProcess (kernel_main.cl:342-359, MathAndSTL.cl:132-169) on the float frame
+__global__ __launch_bounds__(CRT_BLOCK) void crt_postprocess_kernel(CrtFrame F, float4* __restrict__ img)
+{
+    int px, py;
+    if (!lane_pixel(F, px, py)) return;
+    const size_t idx = (size_t)py * (size_t)F.width + (size_t)px;
+    const float uvx = (float)px / (float)F.width, uvy = (float)py / (float)F.height;
+    float4 p = img[idx];
+    v3 rgb = mk3(p.x, p.y, p.z);
+    const float P = sqrtf((rgb.x * rgb.x) * 0.299f + ((rgb.y * rgb.y) * 0.587f) + ((rgb.z * rgb.z) * 0.114f));
+    const v3 Pv = mk3(P, P, P);
+    rgb = add3(Pv, scale3(sub3(rgb, Pv), 1.2f));
+    const v3 lw = mk3(0.2126f, 0.7152f, 0.0722f);
+    const float max_white_l = 0.8f;
+    const float l_old = dot3(rgb, lw);
+    const float numerator = l_old * (1.0f + (l_old / (max_white_l * max_white_l)));
+    const float l_new = numerator / (1.0f + l_old);
+    const float l_in = dot3(rgb, lw);
+    rgb = scale3(rgb, l_new / l_in);
+    const float ig = 1.0f / 1.55f;
+    rgb = mk3(powf(rgb.x, ig), powf(rgb.y, ig), powf(rgb.z, ig));
+    const float oneDivGamma = 1.0f / 1.2f;
+    rgb = mk3(powf(rgb.x, oneDivGamma), powf(rgb.y, oneDivGamma), powf(rgb.z, oneDivGamma));
+    const float vx = uvx * (1.0f - uvy), vy = uvy * (1.0f - uvx);
+    float vig = (vx * vy) * 15.0f;
+    vig = powf(vig, 0.15f);
+    rgb = scale3(rgb, vig);
+    img[idx] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+}
+
+// closest-hit query over explicit rays (hit-record parity)
+__global__ __launch_bounds__(CRT_BLOCK) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
+                                                              const float* __restrict__ dirs, int n,
+                                                              CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
+{
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    uint32_t* stack = s_stack + threadIdx.x;
+    LaneCounters lc; zero_counters(lc);
+    const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    if (k < n) {
+        v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
+        v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
+        lc.rays++;
+        Closest c = closest_hit<true>(S, o, d, stack, lc);
+        CrtRayHit h;
+        if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
+        else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }
+        out[k] = h;
+    }
+    flush_counters(lc, counters);
+}
+
+// ---- relayout kernels (reference layout -> CDNA4 layout) ----
+__global__ void crt_relayout_tris(const CrtTri* __restrict__ raw, size_t first, size_t count,
+                                  float* __restrict__ hot, uint4* __restrict__ cold)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const size_t i = first + k;
+    const CrtTri t = raw[i];
+    float* h = hot + i * 9;
+    h[0] = t.v0[0]; h[1] = t.v0[1]; h[2] = t.v0[2];
+    h[3] = t.v1[0] - t.v0[0]; h[4] = t.v1[1] - t.v0[1]; h[5] = t.v1[2] - t.v0[2];   // edge1 = y - x
+    h[6] = t.v2[0] - t.v0[0]; h[7] = t.v2[1] - t.v0[1]; h[8] = t.v2[2] - t.v0[2];   // edge2 = z - x
+    const uint4* tail = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(raw + i) + 48);
+    cold[i * 2] = tail[0];
+    cold[i * 2 + 1] = tail[1];
+}
+
+__device__ __forceinline__ uint32_t make_ref(const CrtBVHNode& n, uint32_t self, uint32_t nodeCount, uint32_t triCap,
+                                             uint32_t* bigLeaf, int* err)
+{
+    if (n.triCount > 0) {
+        if ((uint64_t)n.leftFirst + (uint64_t)n.triCount > (uint64_t)triCap || n.leftFirst > 0x00FFFFFFu) { atomicOr(err, 1); return CRT_LEAF_BIT | (1u << 24); }
+        if (n.triCount < 128u) return CRT_LEAF_BIT | (n.triCount << 24) | n.leftFirst;
+        bigLeaf[n.leftFirst] = n.triCount;
+        return CRT_LEAF_BIT | n.leftFirst;
+    }
+    // children are always allocated after their parent (BVH.cpp:203-204): enforces an acyclic graph
+    if (n.leftFirst <= self || (uint64_t)n.leftFirst + 1 >= (uint64_t)nodeCount) { atomicOr(err, 2); return CRT_LEAF_BIT | (1u << 24); }
+    return n.leftFirst >> 1;
+}
+
+__global__ void crt_relayout_nodes(const CrtBVHNode* __restrict__ raw, uint32_t nodeCount, uint32_t triCap,
+                                   float4* __restrict__ pairs, uint32_t* __restrict__ bigLeaf, int* __restrict__ err)
+{
+    uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nodeCount) return;
+    const CrtBVHNode node = raw[n];
+    if (node.triCount > 0) return;
+    const uint32_t l = node.leftFirst;
+    if (l <= n || (uint64_t)l + 1 >= (uint64_t)nodeCount) { atomicOr(err, 2); return; }
+    const CrtBVHNode L = raw[l], R = raw[l + 1];
+    const uint32_t lref = make_ref(L, l, nodeCount, triCap, bigLeaf, err);
+    const uint32_t rref = make_ref(R, l + 1, nodeCount, triCap, bigLeaf, err);
+    float4* p = pairs + (size_t)(l >> 1) * 4;
+    p[0] = make_float4(L.aabbMin[0], L.aabbMin[1], L.aabbMin[2], __uint_as_float(lref));
+    p[1] = make_float4(L.aabbMax[0], L.aabbMax[1], L.aabbMax[2], 0.0f);
+    p[2] = make_float4(R.aabbMin[0], R.aabbMin[1], R.aabbMin[2], __uint_as_float(rref));
+    p[3] = make_float4(R.aabbMax[0], R.aabbMax[1], R.aabbMax[2], 0.0f);
+}
+
+__global__ void crt_make_root_refs(const CrtBVHNode* __restrict__ raw, uint32_t nodeCount, uint32_t triCap,
+                                   const uint32_t* __restrict__ roots, uint32_t numRoots,
+                                   uint32_t* __restrict__ rootRefs, uint32_t* __restrict__ bigLeaf, int* __restrict__ err)
+{
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= numRoots) return;
+    const uint32_t r = roots[k];
+    if (r >= nodeCount) { rootRefs[k] = CRT_LEAF_BIT | (1u << 24); return; } // not (yet) uploaded: harmless dummy, flagged at render
+    rootRefs[k] = make_ref(raw[r], r, nodeCount, triCap, bigLeaf, err);
+}
+
+__global__ void crt_relayout_texels(const uint8_t* __restrict__ raw, size_t firstTexel, size_t count, uint32_t* __restrict__ texels)
+{
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const size_t i = firstTexel + k;
+    const uint8_t* p = raw + i * 3;
+    texels[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host state
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct State {
+    bool initialized = false;
+    int device = -1;
+    char deviceName[256] = { 0 };
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    int width = 0, height = 0;
+    int bandRows = 16, rank = 0, nRanks = 1;
+    // raw (reference-layout) device copies
+    CrtTri* rawTris = nullptr; CrtBVHNode* rawNodes = nullptr; uint32_t* roots = nullptr; uint8_t* rawTexels = nullptr;
+    // CDNA4 layouts
+    float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
+    uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr;
+    CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
+    float* rays = nullptr; float4* out = nullptr;
+    unsigned long long* counters = nullptr; int* err = nullptr;
+    void* queryBuf = nullptr; size_t queryBytes = 0;
+    size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
+    uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
+    bool sceneValid = true;
+    float ms[4] = { 0, 0, 0, 0 };
+    bool timed[4] = { false, false, false, false };
+    bool pendingTiming = false; int pendingFlags = 0;
+    CrtCounters lastCounters;
+};
+State g;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return (int)e_; } } while (0)
+
+int owned_tile_rows()
+{
+    const int totalTileRows = (g.height + CRT_TILE - 1) / CRT_TILE;
+    const int tpb = g.bandRows / CRT_TILE;
+    int n = 0;
+    for (int r = 0; r < totalTileRows; ++r) if (((r / tpb) % g.nRanks) == g.rank) ++n;
+    return n;
+}
+
+void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, const float* invProj)
+{
+    memset(&F, 0, sizeof F);
+    if (invView) memcpy(F.invView, invView, 64);
+    if (invProj) memcpy(F.invProj, invProj, 64);
+    if (args) {
+        memcpy(F.camPos, args->cameraPos, 12);
+        F.lightY = (float)sin((double)args->sunAngle);
+        F.lightZ = (float)cos((double)args->sunAngle);
+    }
+    F.width = g.width; F.height = g.height;
+    F.tilesX = (g.width + CRT_TILE - 1) / CRT_TILE;
+    F.numTiles = F.tilesX * owned_tile_rows();
+    F.chunk = (F.numTiles + 7) / 8;
+    F.tileRowsPerBand = g.bandRows / CRT_TILE;
+    F.rank = g.rank; F.nRanks = g.nRanks;
+}
+
+void fill_scene(CrtDevScene& S, uint32_t numInstances)
+{
+    S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs;
+    S.instances = g.instances; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
+    S.numTexels = (int)((g.texelBytesHigh + 2) / 3);
+    if (S.numTexels < 1) S.numTexels = 1;
+    S.numInstances = numInstances;
+}
+
+int alloc_frame_buffers(int w, int h)
+{
+    if (g.rays) { hipFree(g.rays); g.rays = nullptr; }
+    if (g.out) { hipFree(g.out); g.out = nullptr; }
+    HIPCHK(hipMalloc(&g.rays, sizeof(float) * 3 * (size_t)w * (size_t)h));
+    HIPCHK(hipMalloc(&g.out, sizeof(float4) * (size_t)w * (size_t)h));
+    HIPCHK(hipMemsetAsync(g.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.width = w; g.height = h;
+    return CRT_OK;
+}
+
+int rebuild_bvh_layout()
+{
+    HIPCHK(hipMemsetAsync(g.err, 0, sizeof(int), g.stream));
+    if (g.nodeCount) {
+        crt_relayout_nodes<<<(g.nodeCount + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.pairs, g.bigLeaf, g.err);
+        HIPCHK(hipGetLastError());
+    }
+    if (g.numRoots) {
+        crt_make_root_refs<<<(g.numRoots + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.roots, g.numRoots, g.rootRefs, g.bigLeaf, g.err);
+        HIPCHK(hipGetLastError());
+    }
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(&err, g.err, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.sceneValid = (err == 0);
+    return err ? CRT_E_BAD_ARGUMENT : CRT_OK;
+}
+
+int collect_timing()
+{
+    if (!g.pendingTiming) return CRT_OK;
+    HIPCHK(hipEventSynchronize(g.ev[4]));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, g.ev[0], g.ev[4])); g.ms[0] = t;
+    HIPCHK(hipEventElapsedTime(&t, g.ev[0], g.ev[1])); g.ms[1] = t;
+    HIPCHK(hipEventElapsedTime(&t, g.ev[1], g.ev[2])); g.ms[2] = t;
+    HIPCHK(hipEventElapsedTime(&t, g.ev[2], g.ev[3])); g.ms[3] = t;
+    if (g.pendingFlags & CRT_RENDER_COUNTERS) {
+        unsigned long long c[12];
+        HIPCHK(hipMemcpy(c, g.counters, sizeof c, hipMemcpyDeviceToHost));
+        CrtCounters& o = g.lastCounters;
+        o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
+        o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
+    }
+    g.pendingTiming = false;
+    return CRT_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* crt_error_string(int code)
+{
+    switch (code) {
+    case CRT_OK: return "ok";
+    case CRT_E_NOT_INITIALIZED: return "crt: not initialized (crt_init failed or was not called)";
+    case CRT_E_BAD_ARGUMENT: return "crt: bad argument or invalid scene data";
+    case CRT_E_OUT_OF_RANGE: return "crt: upload exceeds a fixed device pool";
+    case CRT_E_NO_DEVICE: return "crt: no usable HIP device";
+    case CRT_E_UNSUPPORTED: return "crt: unsupported";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "crt: unknown error";
+    }
+}
+
+const char* crt_device_name(void) { return g.deviceName; }
+
+int crt_init(int device, int width, int height)
+{
+    if (g.initialized) return CRT_E_BAD_ARGUMENT;
+    if (width < 16 || height < 16) return CRT_E_BAD_ARGUMENT;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CRT_E_NO_DEVICE;
+    if (device < 0 || device >= n) return CRT_E_BAD_ARGUMENT;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(g.deviceName, sizeof g.deviceName, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    g.device = device;
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&g.ev[i]));
+
+    g.triCap = (size_t)CRT_MAX_TRIANGLES * 2;           // ResourceManager.cpp:158
+    g.nodeCap = (size_t)CRT_MAX_TRIANGLES * 2;          // ResourceManager.cpp:159 (MAX_BVHMEMORY * 2)
+    g.texelByteCap = CRT_MAX_TEXTURE_BYTES * 2;         // ResourceManager.cpp:163
+    HIPCHK(hipMalloc(&g.rawTris, g.triCap * sizeof(CrtTri)));
+    HIPCHK(hipMalloc(&g.rawNodes, g.nodeCap * sizeof(CrtBVHNode)));
+    HIPCHK(hipMalloc(&g.roots, CRT_MAX_MESHES * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.rawTexels, g.texelByteCap + 16));
+    HIPCHK(hipMalloc(&g.pairs, (g.nodeCap / 2 + 1) * 4 * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.triHot, g.triCap * 9 * sizeof(float)));
+    HIPCHK(hipMalloc(&g.triCold, g.triCap * 2 * sizeof(uint4)));
+    HIPCHK(hipMalloc(&g.bigLeaf, g.triCap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.rootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
+    HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
+    HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
+    HIPCHK(hipMalloc(&g.counters, 12 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g.err, sizeof(int)));
+    HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
+    HIPCHK(hipMemset(g.rootRefs, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
+    HIPCHK(hipMemset(g.instances, 0, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
+    HIPCHK(hipMemset(g.materials, 0, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
+    HIPCHK(hipMemset(g.textures, 0, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
+    HIPCHK(hipMemset(g.texels, 0, 64));
+    g.nodeCount = 0; g.numRoots = 0; g.texelBytesHigh = 0; g.trisHigh = 0; g.sceneValid = true;
+    g.bandRows = 16; g.rank = 0; g.nRanks = 1;
+    int rc = alloc_frame_buffers(width, height);
+    if (rc) return rc;
+    g.initialized = true;
+    // default white / black texels (ResourceManager.cpp:168-177)
+    const unsigned char def[6] = { 0xFF, 0xFF, 0xFF, 0, 0, 0 };
+    return crt_upload_texels(def, 0, 6);
+}
+
+int crt_shutdown(void)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    hipStreamSynchronize(g.stream);
+    void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
+                     g.texels, g.instances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf };
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (int i = 0; i < 5; ++i) if (g.ev[i]) hipEventDestroy(g.ev[i]);
+    if (g.stream) hipStreamDestroy(g.stream);
+    g = State();
+    return CRT_OK;
+}
+
+int crt_resize(int width, int height)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (width < 16 || height < 16) return CRT_OK; // Renderer.cpp:200
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return alloc_frame_buffers(width, height);
+}
+
+int crt_set_row_bands(int bandRows, int rank, int nRanks)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
+    g.bandRows = bandRows; g.rank = rank; g.nRanks = nRanks;
+    return CRT_OK;
+}
+
+int crt_owned_rows(void)
+{
+    if (!g.initialized) return 0;
+    int rows = 0;
+    const int tpb = g.bandRows / CRT_TILE;
+    for (int y = 0; y < g.height; ++y) if ((((y / CRT_TILE) / tpb) % g.nRanks) == g.rank) ++rows;
+    return rows;
+}
+
+int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (bytes == 0) return CRT_OK;
+    if (!tris || byteOffset % sizeof(CrtTri) || bytes % sizeof(CrtTri)) return CRT_E_BAD_ARGUMENT;
+    if (byteOffset + bytes > g.triCap * sizeof(CrtTri)) return CRT_E_OUT_OF_RANGE;
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(g.rawTris) + byteOffset, tris, bytes, hipMemcpyHostToDevice, g.stream));
+    const size_t first = byteOffset / sizeof(CrtTri), count = bytes / sizeof(CrtTri);
+    crt_relayout_tris<<<(unsigned)((count + 255) / 256), 256, 0, g.stream>>>(g.rawTris, first, count, g.triHot, g.triCold);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (first + count > g.trisHigh) g.trisHigh = first + count;
+    return CRT_OK;
+}
+
+int crt_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (bytes == 0) return CRT_OK;
+    if (!nodes || byteOffset % sizeof(CrtBVHNode) || bytes % sizeof(CrtBVHNode)) return CRT_E_BAD_ARGUMENT;
+    if (byteOffset + bytes > g.nodeCap * sizeof(CrtBVHNode)) return CRT_E_OUT_OF_RANGE;
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(g.rawNodes) + byteOffset, nodes, bytes, hipMemcpyHostToDevice, g.stream));
+    const uint32_t high = (uint32_t)((byteOffset + bytes) / sizeof(CrtBVHNode));
+    if (high > g.nodeCount) g.nodeCount = high;
+    return rebuild_bvh_layout();
+}
+
+int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (count == 0) return CRT_OK;
+    if (!roots) return CRT_E_BAD_ARGUMENT;
+    if (firstMesh + count > CRT_MAX_MESHES) return CRT_E_OUT_OF_RANGE;
+    HIPCHK(hipMemcpyAsync(g.roots + firstMesh, roots, count * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    if (firstMesh + count > g.numRoots) g.numRoots = (uint32_t)(firstMesh + count);
+    return rebuild_bvh_layout();
+}
+
+int crt_upload_materials(const void* materials, size_t first, size_t count)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (count == 0) return CRT_OK;
+    if (!materials) return CRT_E_BAD_ARGUMENT;
+    if (first + count > CRT_MAX_MATERIALS) return CRT_E_OUT_OF_RANGE;
+    HIPCHK(hipMemcpyAsync(g.materials + first, materials, count * sizeof(CrtMaterial), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
+}
+
+int crt_upload_texture_table(const void* textures, size_t count)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (count == 0) return CRT_OK;
+    if (!textures) return CRT_E_BAD_ARGUMENT;
+    if (count > CRT_MAX_TEXTURES) return CRT_E_OUT_OF_RANGE;
+    HIPCHK(hipMemcpyAsync(g.textures, textures, count * sizeof(CrtTexture), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
+}
+
+int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (bytes == 0) return CRT_OK;
+    if (!rgb8) return CRT_E_BAD_ARGUMENT;
+    if (byteOffset + bytes > g.texelByteCap) return CRT_E_OUT_OF_RANGE;
+    HIPCHK(hipMemcpyAsync(g.rawTexels + byteOffset, rgb8, bytes, hipMemcpyHostToDevice, g.stream));
+    if (byteOffset + bytes > g.texelBytesHigh) g.texelBytesHigh = byteOffset + bytes;
+    const size_t firstTexel = byteOffset / 3;
+    const size_t endTexel = (byteOffset + bytes) / 3;       // whole texels only; a trailing partial texel waits for its bytes
+    if (endTexel > firstTexel) {
+        const size_t count = endTexel - firstTexel;
+        crt_relayout_texels<<<(unsigned)((count + 255) / 256), 256, 0, g.stream>>>(g.rawTexels, firstTexel, count, g.texels);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
+}
+
+int crt_upload_instances(const void* instances, size_t first, size_t count)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (count == 0) return CRT_OK;
+    if (!instances) return CRT_E_BAD_ARGUMENT;
+    if (first + count > CRT_MAX_INSTANCES) return CRT_E_OUT_OF_RANGE;
+    const CrtMeshInstance* in = static_cast<const CrtMeshInstance*>(instances);
+    for (size_t i = 0; i < count; ++i) if (in[i].meshIndex >= CRT_MAX_MESHES) return CRT_E_BAD_ARGUMENT;
+    HIPCHK(hipMemcpyAsync(g.instances + first, instances, count * sizeof(CrtMeshInstance), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
+}
+
+int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!args || !invView || !invProj) return CRT_E_BAD_ARGUMENT;
+    if (args->numMeshes > CRT_MAX_INSTANCES) return CRT_E_OUT_OF_RANGE;
+    if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
+    int rc = collect_timing();
+    if (rc) return rc;
+    CrtFrame F; fill_frame(F, args, invView, invProj);
+    CrtDevScene S; fill_scene(S, args->numMeshes);
+    if (F.numTiles == 0) return CRT_OK;
+    const unsigned grid = (unsigned)F.chunk * 8u;
+
+    HIPCHK(hipEventRecord(g.ev[0], g.stream));
+    if (flags & CRT_RENDER_WRITE_RAYS) {
+        crt_raygen_kernel<<<grid, CRT_BLOCK, 0, g.stream>>>(F, g.rays);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(g.ev[1], g.stream));
+    if (flags & CRT_RENDER_COUNTERS) {
+        HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
+        crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
+    } else {
+        crt_trace_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(g.ev[2], g.stream));
+    if (flags & CRT_RENDER_POSTPROCESS) {
+        crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, g.stream>>>(F, g.out);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(g.ev[3], g.stream));
+    HIPCHK(hipEventRecord(g.ev[4], g.stream));
+    g.pendingTiming = true; g.pendingFlags = flags;
+    if (!(flags & CRT_RENDER_ASYNC)) return crt_sync();   // the reference's clFinish (Renderer.cpp:367)
+    return CRT_OK;
+}
+
+int crt_sync(void)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return collect_timing();
+}
+
+int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (n <= 0) return CRT_OK;
+    if (!origins || !dirs || !out || numInstances > CRT_MAX_INSTANCES) return CRT_E_BAD_ARGUMENT;
+    if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
+    int rc = collect_timing();
+    if (rc) return rc;
+    const size_t rayBytes = sizeof(float) * 3 * (size_t)n, need = rayBytes * 2 + sizeof(CrtRayHit) * (size_t)n;
+    if (need > g.queryBytes) {
+        if (g.queryBuf) hipFree(g.queryBuf);
+        g.queryBuf = nullptr; g.queryBytes = 0;
+        HIPCHK(hipMalloc(&g.queryBuf, need));
+        g.queryBytes = need;
+    }
+    float* dO = static_cast<float*>(g.queryBuf);
+    float* dD = dO + 3 * (size_t)n;
+    CrtRayHit* dH = reinterpret_cast<CrtRayHit*>(dD + 3 * (size_t)n);
+    HIPCHK(hipMemcpyAsync(dO, origins, rayBytes, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(dD, dirs, rayBytes, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
+    CrtDevScene S; fill_scene(S, numInstances);
+    crt_query_kernel<<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dH, sizeof(CrtRayHit) * (size_t)n, hipMemcpyDeviceToHost, g.stream));
+    unsigned long long c[12];
+    HIPCHK(hipMemcpyAsync(c, g.counters, sizeof c, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    CrtCounters& o = g.lastCounters;
+    o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
+    o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
+    return CRT_OK;
+}
+
+int crt_read_output(float* dst, size_t floats)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!dst || floats != (size_t)g.width * (size_t)g.height * 4) return CRT_E_BAD_ARGUMENT;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(dst, g.out, floats * sizeof(float), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_read_output_rows(float* dst, int row0, int rows)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!dst || row0 < 0 || rows < 0 || row0 + rows > g.height) return CRT_E_BAD_ARGUMENT;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(dst, g.out + (size_t)row0 * (size_t)g.width, (size_t)rows * (size_t)g.width * sizeof(float4), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_read_rays(float* dst, size_t floats)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!dst || floats != (size_t)g.width * (size_t)g.height * 3) return CRT_E_BAD_ARGUMENT;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(dst, g.rays, floats * sizeof(float), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+void* crt_output_device_ptr(void) { return g.initialized ? (void*)g.out : nullptr; }
+
+float crt_last_kernel_ms(int which)
+{
+    if (!g.initialized || which < 0 || which > 3) return -1.0f;
+    if (collect_timing() != CRT_OK) return -1.0f;
+    return g.ms[which];
+}
+
+int crt_get_counters(CrtCounters* out)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!out) return CRT_E_BAD_ARGUMENT;
+    int rc = collect_timing();
+    if (rc) return rc;
+    *out = g.lastCounters;
+    return CRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,171 @@
+"""Headless driver: the reference's call order over the mirrored host API.
+
+``Session`` replaces ``EngineMain.cpp:5-23`` + ``Engine.cpp:56-80``: initialise the renderer, load a
+scene through ResourceManager (PrepareMeshes -> ImportTexture(skybox) -> ImportMesh... ->
+PushMeshesToGPU -> PushTexturesToGPU -> Begin/Register/EndInstanceRegister) and render frames.
+It only forwards to ``libcrt_host.so`` / ``libcrt_hip.so``; there is no Python compute path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CrtCounters, CrtError, CrtTraceArgs
+
+
+class Session:
+    def __init__(self, width, height, device=0, host_only=False):
+        self.h = _lib.host()
+        self.hip = _lib.hip()
+        self.width, self.height = int(width), int(height)
+        self.host_only = bool(host_only)
+        self.scene = None
+        ok = self.h.crth_initialize_host_only(self.width, self.height) if host_only else self.h.crth_initialize(int(device), self.width, self.height)
+        if not ok:
+            rc = self.h.crth_last_error()
+            raise CrtError(f"Renderer::Initialize failed ({rc}): {self.hip.crt_error_string(rc).decode()}")
+        self.open = True
+
+    # ---- lifecycle ----
+    def close(self):
+        if self.open:
+            self.h.crth_terminate()
+            self.open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, what):
+        rc = self.h.crth_last_error()
+        if rc:
+            raise CrtError(f"{what}: error {rc}: {self.hip.crt_error_string(rc).decode()}")
+
+    # ---- scene ----
+    def load_scene(self, scene):
+        h = self.h
+        h.crth_prepare_meshes()
+        tex = h.crth_import_texture(scene.skybox.encode())   # must be texture index 2 (Engine.cpp:60-61)
+        self._check("ImportTexture(skybox)")
+        assert tex == 2, tex
+        handles = []
+        for path in scene.meshes:
+            handles.append(h.crth_import_mesh(path.encode()))
+            self._check(f"ImportMesh({path})")
+        h.crth_push_meshes()
+        h.crth_push_textures()
+        self._check("PushMeshesToGPU/PushTexturesToGPU")
+        h.crth_begin_instances()
+        for inst in scene.instances:
+            p, keep = _lib.fptr(inst.matrix)
+            h.crth_register_instance(handles[inst.mesh], int(inst.material), p)
+        h.crth_end_instances()
+        self._check("RegisterMeshInstance")
+        self.set_camera(scene.camera_pos, scene.camera_front)
+        self.scene = scene
+        return handles
+
+    def set_camera(self, pos, front):
+        p, k1 = _lib.fptr(np.asarray(pos, np.float32))
+        f, k2 = _lib.fptr(np.asarray(front, np.float32))
+        self.h.crth_set_camera(p, f)
+
+    def camera(self):
+        iv = np.zeros(16, np.float32); ip = np.zeros(16, np.float32); pos = np.zeros(3, np.float32)
+        self.h.crth_get_camera(iv.ctypes.data_as(C.POINTER(C.c_float)), ip.ctypes.data_as(C.POINTER(C.c_float)), pos.ctypes.data_as(C.POINTER(C.c_float)))
+        return iv, ip, pos
+
+    def resize(self, width, height):
+        self.h.crth_resize(int(width), int(height))
+        self._check("OnWindowResize")
+        if width >= 16 and height >= 16:
+            self.width, self.height = int(width), int(height)
+
+    # ---- rendering through the mirrored Renderer ----
+    def render(self, sun_angle=None, postprocess=False):
+        self.h.crth_set_postprocess(1 if postprocess else 0)
+        frame = self.h.crth_render(float(self.scene.sun_angle if sun_angle is None else sun_angle))
+        if frame == 0:
+            self._check("Renderer::Render")
+            raise CrtError("Renderer::Render failed")
+        return frame
+
+    def output(self):
+        ptr = self.h.crth_map_output()
+        if not ptr:
+            self._check("Renderer::MapOutput")
+            raise CrtError("Renderer::MapOutput returned null")
+        return _lib.as_array(ptr, self.width * self.height * 4, np.float32).reshape(self.height, self.width, 4)
+
+    # ---- direct C-ABI access (same device state the mirror drives) ----
+    def trace_args(self, sun_angle=None):
+        iv, ip, pos = self.camera()
+        a = CrtTraceArgs()
+        a.cameraPos[0], a.cameraPos[1], a.cameraPos[2] = float(pos[0]), float(pos[1]), float(pos[2])
+        a.time = 0.0
+        a.numMeshes = self.h.crth_num_instances()
+        a.sunAngle = float(self.scene.sun_angle if sun_angle is None else sun_angle)
+        return a, iv, ip
+
+    def render_raw(self, flags=0, sun_angle=None):
+        a, iv, ip = self.trace_args(sun_angle)
+        _lib.check(self.hip.crt_render(C.byref(a), iv.ctypes.data_as(C.POINTER(C.c_float)), ip.ctypes.data_as(C.POINTER(C.c_float)), int(flags)), "crt_render")
+
+    def sync(self):
+        _lib.check(self.hip.crt_sync(), "crt_sync")
+
+    def read_output(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        _lib.check(self.hip.crt_read_output(out.ctypes.data, out.size), "crt_read_output")
+        return out
+
+    def read_rays(self):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        _lib.check(self.hip.crt_read_rays(out.ctypes.data, out.size), "crt_read_rays")
+        return out
+
+    def counters(self):
+        c = CrtCounters()
+        _lib.check(self.hip.crt_get_counters(C.byref(c)), "crt_get_counters")
+        return c.as_dict()
+
+    def kernel_ms(self, which=2):
+        return float(self.hip.crt_last_kernel_ms(int(which)))
+
+    def query_hits(self, origins, dirs):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros(len(o), _lib.RAYHIT_DTYPE)
+        _lib.check(self.hip.crt_query_hits(o.ctypes.data, d.ctypes.data, len(o), self.h.crth_num_instances(), out.ctypes.data), "crt_query_hits")
+        return out
+
+    def set_row_bands(self, band_rows, rank, n_ranks):
+        self.h.crth_set_row_bands(int(band_rows), int(rank), int(n_ranks))
+        self._check("SetRowBands")
+
+    def owned_rows(self):
+        return int(self.hip.crt_owned_rows())
+
+    # ---- host arenas (for the oracle in tests) ----
+    def arenas(self):
+        h = self.h
+        return {
+            "tris": _lib.as_array(h.crth_triangles(), h.crth_num_triangles(), _lib.TRI_DTYPE),
+            "nodes": _lib.as_array(h.crth_nodes(), h.crth_num_nodes(), _lib.NODE_DTYPE),
+            "roots": _lib.as_array(h.crth_roots(), h.crth_num_meshes(), np.uint32),
+            "materials": _lib.as_array(h.crth_materials(), 256, _lib.MATERIAL_DTYPE),
+            "textures": _lib.as_array(h.crth_textures(), 32, _lib.TEXTURE_DTYPE),
+            "texels": _lib.as_array(h.crth_texels(), h.crth_texel_bytes(), np.uint8),
+            "instances": _lib.as_array(h.crth_instances(), h.crth_num_instances(), _lib.INSTANCE_DTYPE),
+            "num_materials": h.crth_num_materials(),
+            "num_textures": h.crth_num_textures(),
+        }
+
+    def cpu_raycast(self, origins, dirs, nthreads=1):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        out = np.zeros(len(o), _lib.HITRECORD_DTYPE)
+        self.h.crth_cpu_raycast(o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data, int(nthreads))
+        return out

@@ -1,0 +1,46 @@
+// Renderer.hpp -- host mirror of the reference's Renderer namespace (Renderer.hpp:1-46): device
+// init, instance table, per-frame launch. GL/window parts are gone (headless); Render() returns a
+// frame counter instead of a GL texture id and MapOutput() exposes the HDR float4 frame.
+#pragma once
+#include "ResourceManager.hpp"
+
+typedef CrtMeshInstance MeshInstance;
+typedef uint MeshInstanceHandle;
+
+namespace Renderer
+{
+    constexpr uint MaxNumInstances = 401;
+
+    // device: HIP ordinal; width/height: initial frame (the reference takes them from the window)
+    int Initialize(int device = 0, int width = 1249, int height = 720);
+    void Terminate();
+    // one frame: RayGen -> Trace -> PostProcess -> wait (Renderer.cpp:305-375). Returns the frame
+    // index (>0) or 0 on failure (see LastError()).
+    unsigned Render(float sunAngle);
+    void OnWindowResize(int width, int height);
+
+    void BeginInstanceRegister();
+    MeshInstanceHandle RegisterMeshInstance(MeshHandle handle, MaterialHandle material, const Matrix4& mat);
+    MeshInstanceHandle RegisterMeshInstance(MeshHandle handle, MaterialHandle material, float3 position, const Quaternion& rotation, const float3& scale);
+    void EndInstanceRegister();
+    void RemoveMeshInstance(MeshInstanceHandle handle);
+    void ClearAllInstances();
+
+    void SetMeshInstanceMaterial(MeshInstanceHandle meshHandle, MaterialHandle materialHandle);
+    void SetMeshPosition(MeshInstanceHandle handle, float3 position);
+    void SetMeshMatrix(MeshInstanceHandle handle, const Matrix4& matrix);
+    const Camera& GetCamera();
+
+    // ---- additions for the headless build ----
+    Camera& EditCamera();                 // set position/Front, then RecalculateView()
+    void SetPostProcess(bool enabled);    // PostProcess is on upstream; parity is judged pre-post
+    void SetTime(float seconds);          // TraceArgs.time (Window::GetTime upstream)
+    void SetRowBands(int bandRows, int rank, int nRanks); // multi-GPU image tiling
+    const float* MapOutput();             // host copy of the float4 frame (width*height*4), valid until next Render
+    float LastFrameMs();                  // HIP-event time of the last frame's kernels
+    int LastError();
+}
+
+extern uint g_NumMeshInstances;
+extern Matrix4* g_MeshTransforms;
+extern MeshInstance* g_MeshInstances;

@@ -1,0 +1,404 @@
+"""Seeded synthetic scenes for BASELINE.json's configs (definitions: SURVEY.md section 8d).
+
+Every scene is written to disk in the OBJ/MTL subset the reference's importer reads
+(AssetManager.cpp:90-289; textures as binary PPM instead of JPEG) and then loaded through the
+mirrored ``ResourceManager::ImportMesh`` path, so the importer is on the tested path. Generation is
+deterministic (integer-hash noise, no library RNG state) and cached under ``$CRT_SCENE_CACHE``
+(default ``/tmp/crt_scenes``).
+
+    cornell-1k         984 triangles, 1 mesh, 4 materials            (configs 1-2)
+    sponza-class-250k  253,952 triangles, 1 mesh, 8 textures 512^2   (config 3)
+    multi-1M           8 meshes x 125,120 = 1,000,960 triangles, 16 instances, 8 textures 1024^2 (configs 4-5)
+    tiny               small 2-mesh / 3-instance scene for fast tests
+"""
+import os
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+import numpy as np
+
+from . import _lib
+
+CACHE_DIR = os.environ.get("CRT_SCENE_CACHE", "/tmp/crt_scenes")
+VERSION = 4  # bump to invalidate cached scene files
+
+
+# ------------------------------------------------------------------------------------------------
+# deterministic noise
+# ------------------------------------------------------------------------------------------------
+def _hash_u32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x = ((x ^ 61) ^ (x >> 16)) & 0xFFFFFFFF
+    x = (x * 9) & 0xFFFFFFFF
+    x = x ^ (x >> 4)
+    x = (x * 0x27D4EB2D) & 0xFFFFFFFF
+    x = x ^ (x >> 15)
+    return x.astype(np.uint32)
+
+
+def _rand01(seed, *idx):
+    h = np.uint64(seed) * np.uint64(0x9E3779B1)
+    acc = _hash_u32(np.uint64(int(h) & 0xFFFFFFFF))
+    for k, i in enumerate(idx):
+        acc = _hash_u32(acc.astype(np.uint64) * np.uint64(31) + np.asarray(i, dtype=np.int64).astype(np.uint64) * np.uint64(0x85EBCA6B + 2 * k) + np.uint64(k + 1))
+    return (acc >> 8).astype(np.float64) / float(1 << 24)
+
+
+def _value_noise(seed, x, y):
+    x0 = np.floor(x).astype(np.int64)
+    y0 = np.floor(y).astype(np.int64)
+    fx, fy = x - x0, y - y0
+    sx, sy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+    a, b = _rand01(seed, x0, y0), _rand01(seed, x0 + 1, y0)
+    c, d = _rand01(seed, x0, y0 + 1), _rand01(seed, x0 + 1, y0 + 1)
+    return (a + (b - a) * sx) * (1 - sy) + (c + (d - c) * sx) * sy
+
+
+def _fbm(seed, x, y, octaves=5):
+    amp, freq, total, norm = 1.0, 1.0, 0.0, 0.0
+    for o in range(octaves):
+        total = total + amp * _value_noise(seed + 101 * o, x * freq, y * freq)
+        norm += amp
+        amp *= 0.5
+        freq *= 2.0
+    return total / norm
+
+
+# ------------------------------------------------------------------------------------------------
+# mesh primitives (indexed: positions, uvs, normals share one index per vertex)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Mesh:
+    pos: np.ndarray          # (V,3) f32
+    uv: np.ndarray           # (V,2) f32
+    nrm: np.ndarray          # (V,3) f32
+    tri: np.ndarray          # (T,3) i32 vertex indices
+    mat: np.ndarray          # (T,)  i32 material slot
+
+    @staticmethod
+    def concat(meshes):
+        off, ps, us, ns, ts, ms = 0, [], [], [], [], []
+        for m in meshes:
+            ps.append(m.pos); us.append(m.uv); ns.append(m.nrm); ts.append(m.tri + off); ms.append(m.mat)
+            off += len(m.pos)
+        return Mesh(np.concatenate(ps), np.concatenate(us), np.concatenate(ns), np.concatenate(ts), np.concatenate(ms))
+
+
+def _icosphere(level, radius=1.0, center=(0, 0, 0), uv_scale=4.0, mat=0):
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                  [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
+                  [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    for _ in range(level):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        es = np.sort(e, axis=1)
+        key = es[:, 0] * (len(v) + 1) + es[:, 1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        first = np.zeros(len(uniq), dtype=np.int64)
+        first[inv[::-1]] = np.arange(len(key))[::-1]
+        mid = v[es[first, 0]] + v[es[first, 1]]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        base = len(v)
+        v = np.concatenate([v, mid])
+        n = len(f)
+        a, b, c = base + inv[:n], base + inv[n:2 * n], base + inv[2 * n:]
+        f = np.concatenate([np.stack([f[:, 0], a, c], 1), np.stack([f[:, 1], b, a], 1), np.stack([f[:, 2], c, b], 1), np.stack([a, b, c], 1)])
+    uv = np.stack([(np.arctan2(v[:, 0], v[:, 2]) / (2 * np.pi) + 0.5) * uv_scale, (np.arccos(np.clip(v[:, 1], -1, 1)) / np.pi) * uv_scale], 1)
+    pos = v * radius + np.asarray(center, dtype=np.float64)
+    return Mesh(pos.astype(np.float32), uv.astype(np.float32), v.astype(np.float32), f.astype(np.int32), np.full(len(f), mat, np.int32))
+
+
+def _grid(origin, du, dv, nu, nv, normal, uv_scale=1.0, mat=0):
+    """nu x nv quads spanning origin + s*du + t*dv, s,t in [0,1]."""
+    s, t = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="ij")
+    pos = np.asarray(origin, np.float64) + s[..., None] * np.asarray(du, np.float64) + t[..., None] * np.asarray(dv, np.float64)
+    uv = np.stack([s * uv_scale, t * uv_scale], -1)
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tri = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)])
+    nrm = np.broadcast_to(np.asarray(normal, np.float64), pos.shape)
+    return Mesh(pos.reshape(-1, 3).astype(np.float32), uv.reshape(-1, 2).astype(np.float32), nrm.reshape(-1, 3).astype(np.float32),
+                tri.astype(np.int32), np.full(len(tri), mat, np.int32))
+
+
+def _box(lo, hi, mat=0):
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    e = hi - lo
+    X, Y, Z = np.array([e[0], 0, 0]), np.array([0, e[1], 0]), np.array([0, 0, e[2]])
+    faces = [
+        _grid(lo, Z, Y, 1, 1, (-1, 0, 0), mat=mat), _grid(lo + X, Y, Z, 1, 1, (1, 0, 0), mat=mat),
+        _grid(lo, X, Z, 1, 1, (0, -1, 0), mat=mat), _grid(lo + Y, Z, X, 1, 1, (0, 1, 0), mat=mat),
+        _grid(lo, Y, X, 1, 1, (0, 0, -1), mat=mat), _grid(lo + Z, X, Y, 1, 1, (0, 0, 1), mat=mat),
+    ]
+    return Mesh.concat(faces)
+
+
+def _heightfield(n, half_extent, seed, amplitude=2.0, uv_scale=4.0, nmat=1):
+    s, t = np.meshgrid(np.linspace(0, 1, n + 1), np.linspace(0, 1, n + 1), indexing="ij")
+    x, z = (s * 2 - 1) * half_extent, (t * 2 - 1) * half_extent
+    freq = 6.0
+    y = amplitude * _fbm(seed, s * freq, t * freq)
+    eps = 1.0 / n
+    dydx = amplitude * (_fbm(seed, (s + eps) * freq, t * freq) - _fbm(seed, (s - eps) * freq, t * freq)) / (2 * eps * 2 * half_extent)
+    dydz = amplitude * (_fbm(seed, s * freq, (t + eps) * freq) - _fbm(seed, s * freq, (t - eps) * freq)) / (2 * eps * 2 * half_extent)
+    nrm = np.stack([-dydx, np.ones_like(y), -dydz], -1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    pos = np.stack([x, y, z], -1)
+    uv = np.stack([s * uv_scale, t * uv_scale], -1)
+    idx = np.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tri = np.concatenate([np.stack([a, c, b], 1), np.stack([a, d, c], 1)])
+    qi, qj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    qm = ((qi // max(1, n // 4)) + (qj // max(1, n // 4))) % nmat
+    mat = np.concatenate([qm.ravel(), qm.ravel()])
+    return Mesh(pos.reshape(-1, 3).astype(np.float32), uv.reshape(-1, 2).astype(np.float32), nrm.reshape(-1, 3).astype(np.float32),
+                tri.astype(np.int32), mat.astype(np.int32))
+
+
+def _torus(nu, nv, R, r, seed, disp=0.15, uv_scale=4.0, mat=0):
+    s, t = np.meshgrid(np.arange(nu + 1) / nu, np.arange(nv + 1) / nv, indexing="ij")
+    th, ph = s * 2 * np.pi, t * 2 * np.pi
+    # periodic displacement so the seam closes
+    d = disp * (_fbm(seed, (np.cos(th) + 1) * 3 + (np.cos(ph) + 1) * 2, (np.sin(th) + 1) * 3 + (np.sin(ph) + 1) * 2) - 0.5)
+    rr = r + d
+    nx, ny, nz = np.cos(ph) * np.cos(th), np.sin(ph), np.cos(ph) * np.sin(th)
+    pos = np.stack([(R + rr * np.cos(ph)) * np.cos(th), rr * np.sin(ph), (R + rr * np.cos(ph)) * np.sin(th)], -1)
+    nrm = np.stack([nx, ny, nz], -1)
+    uv = np.stack([s * uv_scale, t * uv_scale], -1)
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, dd = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tri = np.concatenate([np.stack([a, c, b], 1), np.stack([a, dd, c], 1)])
+    return Mesh(pos.reshape(-1, 3).astype(np.float32), uv.reshape(-1, 2).astype(np.float32), nrm.reshape(-1, 3).astype(np.float32),
+                tri.astype(np.int32), np.full(len(tri), mat, np.int32))
+
+
+# ------------------------------------------------------------------------------------------------
+# textures
+# ------------------------------------------------------------------------------------------------
+def _texture(seed, size, kind):
+    y, x = np.meshgrid(np.arange(size), np.arange(size), indexing="ij")
+    if kind == "checker":
+        cell = ((x // (size // 16)) + (y // (size // 16))) % 2
+        base = np.where(cell[..., None] == 0, np.array([230, 225, 210]), np.array([60 + 20 * (seed % 5), 90, 140 - 10 * (seed % 7)]))
+        n = _value_noise(seed, x / 7.0, y / 7.0)[..., None]
+        img = base * (0.8 + 0.2 * n)
+    else:
+        n1 = _fbm(seed, x / (size / 8.0), y / (size / 8.0))
+        n2 = _fbm(seed + 17, x / (size / 16.0), y / (size / 16.0))
+        img = np.stack([80 + 160 * n1, 70 + 150 * n2, 60 + 120 * (1 - n1)], -1)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _skybox(width, height):
+    y = np.arange(height)[:, None] / (height - 1.0)
+    x = np.arange(width)[None, :] / (width - 1.0)
+    top, horizon, ground = np.array([70, 130, 230.0]), np.array([225, 235, 245.0]), np.array([95, 85, 75.0])
+    t = np.clip(y * 2, 0, 1)[..., None]
+    b = np.clip(y * 2 - 1, 0, 1)[..., None]
+    img = (top * (1 - t) + horizon * t) * (1 - b) + ground * b
+    img = img * (0.96 + 0.04 * np.cos(x * 2 * np.pi))[..., None]
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def write_ppm(path, img):
+    h, w, _ = img.shape
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(np.ascontiguousarray(img, dtype=np.uint8).tobytes())
+
+
+# ------------------------------------------------------------------------------------------------
+# scene description + files
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class Instance:
+    mesh: int                 # index into Scene.meshes
+    material: int             # 0xFFFF = ResourceManager::DefaultMaterial (mesh's own materials)
+    matrix: np.ndarray        # (4,4) f32 row-major, row-vector convention
+
+
+@dataclass
+class Scene:
+    name: str
+    dir: str
+    skybox: str
+    meshes: List[str]
+    instances: List[Instance]
+    camera_pos: Tuple[float, float, float]
+    camera_front: Tuple[float, float, float]
+    sun_angle: float = -1.96   # Engine.cpp:18
+    num_tris: int = 0
+    extra: dict = field(default_factory=dict)
+
+
+def _mat_name(i):
+    return "mat%02d" % i
+
+
+def _write_mesh(dirpath, stem, mesh: Mesh, materials):
+    """materials: list of (Kd rgb in [0,1], texture file name or None)."""
+    obj = os.path.join(dirpath, stem + ".obj")
+    order = np.argsort(mesh.mat, kind="stable")
+    tri, mat = mesh.tri[order], mesh.mat[order]
+    faces = np.repeat(tri, 3, axis=1).astype(np.int32)  # v/vt/vn share the index
+    names = [_mat_name(i).encode() for i in range(len(materials))]
+    import ctypes as C
+    arr = (C.c_char_p * len(names))(*names)
+    pos = np.ascontiguousarray(mesh.pos, np.float32); uv = np.ascontiguousarray(mesh.uv, np.float32)
+    nrm = np.ascontiguousarray(mesh.nrm, np.float32); faces = np.ascontiguousarray(faces); mat = np.ascontiguousarray(mat, np.int32)
+    rc = _lib.host().crth_write_obj(obj.encode(), pos.ctypes.data, len(pos), uv.ctypes.data, len(uv), nrm.ctypes.data, len(nrm),
+                                    faces.ctypes.data, mat.ctypes.data, len(faces), C.cast(arr, C.c_void_p), len(names))
+    if rc != 0:
+        raise RuntimeError(f"crth_write_obj({obj}) failed: {rc}")
+    with open(os.path.join(dirpath, stem + ".mtl"), "w") as f:
+        f.write("# synthetic materials\n")
+        for i, (kd, tex) in enumerate(materials):
+            f.write("newmtl %s\nNs 50.000000\nd 0.600000\nKd %.6f %.6f %.6f\nKs 0.500000 0.500000 0.500000\n" % (_mat_name(i), kd[0], kd[1], kd[2]))
+            if tex:
+                f.write("map_Kd %s\n" % tex)
+    return obj
+
+
+def _trs(scale, axis, angle, translation):
+    axis = np.asarray(axis, np.float64)
+    axis /= np.linalg.norm(axis)
+    x, y, z = axis
+    c, s = np.cos(angle), np.sin(angle)
+    R = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                  [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                  [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+    M = np.eye(4)
+    M[:3, :3] = (R * scale).T      # row-vector convention: rows are the transformed basis vectors
+    M[3, :3] = translation
+    return M.astype(np.float32)
+
+
+def _done(dirpath):
+    return os.path.exists(os.path.join(dirpath, ".done_v%d" % VERSION))
+
+
+def _mark(dirpath):
+    open(os.path.join(dirpath, ".done_v%d" % VERSION), "w").close()
+
+
+def _normalize(v):
+    v = np.asarray(v, np.float64)
+    return tuple((v / np.linalg.norm(v)).astype(np.float32).tolist())
+
+
+def cornell_1k():
+    d = os.path.join(CACHE_DIR, "cornell-1k")
+    os.makedirs(d, exist_ok=True)
+    sky, obj = os.path.join(d, "sky.ppm"), os.path.join(d, "cornell.obj")
+    if not _done(d):
+        write_ppm(sky, _skybox(512, 256))
+        n = 8
+        parts = [
+            _grid((-1, 0, 1), (2, 0, 0), (0, 0, -2), n, n, (0, 1, 0), mat=0),     # floor
+            _grid((-1, 2, -1), (2, 0, 0), (0, 0, 2), n, n, (0, -1, 0), mat=0),    # ceiling
+            _grid((-1, 0, -1), (2, 0, 0), (0, 2, 0), n, n, (0, 0, 1), mat=0),     # back
+            _grid((-1, 0, 1), (0, 0, -2), (0, 2, 0), n, n, (1, 0, 0), mat=1),     # left (red)
+            _grid((1, 0, -1), (0, 0, 2), (0, 2, 0), n, n, (-1, 0, 0), mat=2),     # right (green)
+            _box((-0.65, 0.0, -0.55), (-0.1, 1.2, 0.0), mat=3),
+            _box((0.15, 0.0, 0.05), (0.7, 0.6, 0.6), mat=3),
+            _icosphere(2, 0.3, (0.42, 0.9, 0.32), mat=0),
+        ]
+        m = Mesh.concat(parts)
+        assert len(m.tri) == 984
+        # The reference's slab test needs tnear < tfar strictly (kernel_main.cl:115), so a node whose box
+        # has zero thickness (axis-aligned planar geometry) can never be entered. Tilt the whole box a
+        # little so that walls and cuboid faces get boxes with volume.
+        ay, ax = 0.15, 0.06
+        Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+        R = Rx @ Ry
+        c = np.array([0.0, 1.0, 0.0])
+        m.pos = ((m.pos.astype(np.float64) - c) @ R.T + c).astype(np.float32)
+        m.nrm = (m.nrm.astype(np.float64) @ R.T).astype(np.float32)
+        _write_mesh(d, "cornell", m, [((0.73, 0.73, 0.73), None), ((0.65, 0.05, 0.05), None), ((0.12, 0.45, 0.15), None), ((0.7, 0.7, 0.3), None)])
+        _mark(d)
+    return Scene("cornell-1k", d, sky, [obj], [Instance(0, 0xFFFF, np.eye(4, dtype=np.float32))],
+                 (0.0, 1.0, 3.5), (0.0, 0.0, -1.0), num_tris=984)
+
+
+def sponza_class_250k():
+    d = os.path.join(CACHE_DIR, "sponza-class-250k")
+    os.makedirs(d, exist_ok=True)
+    sky, obj = os.path.join(d, "sky.ppm"), os.path.join(d, "terrain.obj")
+    if not _done(d):
+        write_ppm(sky, _skybox(1024, 512))
+        texs = []
+        for i in range(8):
+            name = "tex%d.ppm" % i
+            write_ppm(os.path.join(d, name), _texture(7 + i, 512, "checker" if i % 2 == 0 else "noise"))
+            texs.append(name)
+        parts = [_heightfield(256, 48.0, 1234, amplitude=2.0 * 3.0, nmat=4)]
+        for k in range(24):
+            x = (_rand01(1234, k, 0) * 2 - 1) * 40.0
+            z = (_rand01(1234, k, 1) * 2 - 1) * 40.0
+            r = 1.5 + 2.0 * _rand01(1234, k, 2)
+            parts.append(_icosphere(4, float(r), (float(x), float(5.0 + 3.0 * _rand01(1234, k, 3)), float(z)), mat=4 + k % 4))
+        m = Mesh.concat(parts)
+        assert len(m.tri) == 253952
+        kds = [(0.9, 0.9, 0.9), (0.8, 0.7, 0.6), (0.6, 0.8, 0.7), (0.9, 0.8, 0.5), (0.9, 0.4, 0.3), (0.3, 0.5, 0.9), (0.5, 0.9, 0.4), (0.8, 0.8, 0.8)]
+        _write_mesh(d, "terrain", m, [(kds[i], texs[i]) for i in range(8)])
+        _mark(d)
+    return Scene("sponza-class-250k", d, sky, [obj], [Instance(0, 0xFFFF, np.eye(4, dtype=np.float32))],
+                 (0.0, 12.0, 60.0), _normalize((0.0, -0.12, -1.0)), num_tris=253952)
+
+
+def _multi(name, nmesh, ico_level, torus_uv, tex_size, sky_size, ninst):
+    d = os.path.join(CACHE_DIR, name)
+    os.makedirs(d, exist_ok=True)
+    sky = os.path.join(d, "sky.ppm")
+    objs = [os.path.join(d, "mesh%d.obj" % i) for i in range(nmesh)]
+    if not _done(d):
+        write_ppm(sky, _skybox(*sky_size))
+        for i in range(nmesh):
+            seed = 100 + i
+            tex = "tex%d.ppm" % i
+            write_ppm(os.path.join(d, tex), _texture(seed, tex_size, "checker" if i % 2 else "noise"))
+            ico = _icosphere(ico_level, 1.6, (0, 0, 0), mat=0)
+            # displace the sphere radially (seeded), keep normals radial
+            dirs = ico.nrm.astype(np.float64)
+            bump = 1.0 + 0.12 * (_fbm(seed, (dirs[:, 0] + 1.5) * 3, (dirs[:, 1] + dirs[:, 2] * 0.7 + 2.5) * 3) - 0.5)
+            ico.pos = (dirs * 1.6 * bump[:, None]).astype(np.float32)
+            tor = _torus(torus_uv[0], torus_uv[1], 2.6, 0.55, seed, mat=1)
+            m = Mesh.concat([ico, tor])
+            kd0 = (0.55 + 0.4 * float(_rand01(seed, 0)), 0.55 + 0.4 * float(_rand01(seed, 1)), 0.55 + 0.4 * float(_rand01(seed, 2)))
+            kd1 = (0.9, 0.85 - 0.05 * (i % 3), 0.6 + 0.05 * (i % 5))
+            _write_mesh(d, "mesh%d" % i, m, [(kd0, tex), (kd1, None)])
+        _mark(d)
+    insts = []
+    per_row = int(np.ceil(np.sqrt(ninst)))
+    for k in range(ninst):
+        mesh = k % nmesh
+        gx, gz = k % per_row, k // per_row
+        scale = 0.5 + 1.5 * float(_rand01(555, k, 0))
+        axis = (float(_rand01(555, k, 1)) - 0.5, float(_rand01(555, k, 2)) + 0.2, float(_rand01(555, k, 3)) - 0.5)
+        angle = 2 * np.pi * float(_rand01(555, k, 4))
+        tx = (gx - (per_row - 1) / 2.0) * 7.5 + 2.0 * (float(_rand01(555, k, 5)) - 0.5)
+        tz = -(gz * 7.5) + 2.0 * (float(_rand01(555, k, 6)) - 0.5)
+        ty = 3.0 + 3.0 * float(_rand01(555, k, 7))
+        insts.append(Instance(mesh, 0xFFFF, _trs(scale, axis, angle, (tx, ty, tz))))
+    ntri = nmesh * (20 * 4 ** ico_level + 2 * torus_uv[0] * torus_uv[1])
+    return Scene(name, d, sky, objs, insts, (0.0, 10.5, 11.5), _normalize((0.0, -0.5, -1.0)), num_tris=ntri)
+
+
+def multi_1m():
+    return _multi("multi-1M", 8, 6, (180, 120), 1024, (2048, 1024), 16)
+
+
+def tiny():
+    """2 meshes (icosphere L2 + torus 16x8 each), 3 instances; for fast CPU/GPU tests."""
+    return _multi("tiny", 2, 2, (16, 8), 64, (64, 32), 3)
+
+
+SCENES = {"cornell-1k": cornell_1k, "sponza-class-250k": sponza_class_250k, "multi-1M": multi_1m, "tiny": tiny}
+
+
+def get(name) -> Scene:
+    return SCENES[name]()

@@ -1,0 +1,110 @@
+/* crt_api.h -- C-ABI of the MI355X ray-trace path (libcrt_hip.so).
+ *
+ * This is the drop-in boundary: every entry point replaces one group of OpenCL call sites of the
+ * reference's Renderer.cpp / ResourceManager.cpp (cited per function, paths relative to the
+ * upstream tree CLRayTracer/...). Plain pointers and sizes only; buffers are passed in the
+ * reference's own struct layouts (crt_types.h) and re-laid-out for CDNA4 on the device.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t on a HIP failure, or a negative
+ *     CRT_E_* code for argument/state errors; crt_error_string() explains either.
+ *   - state is process-global and NOT thread-safe, like the reference's file-static state
+ *     (Renderer.cpp:23-39, ResourceManager.cpp:49-90). One process drives one GPU.
+ *   - host pointers only need to stay valid for the duration of the call (uploads are
+ *     synchronous; the reference's CL_FALSE writes required the arenas to outlive the queue).
+ *   - there is no CPU fallback: without a usable GPU crt_init fails and everything else returns
+ *     CRT_E_NOT_INITIALIZED.
+ */
+#ifndef CRT_API_H
+#define CRT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "crt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    CRT_OK = 0,
+    CRT_E_NOT_INITIALIZED = -1,
+    CRT_E_BAD_ARGUMENT    = -2,
+    CRT_E_OUT_OF_RANGE    = -3,   /* upload beyond a fixed-size device pool */
+    CRT_E_NO_DEVICE       = -4,
+    CRT_E_UNSUPPORTED     = -5
+};
+
+/* crt_render flags */
+enum {
+    CRT_RENDER_POSTPROCESS = 1,   /* also run PostProcess (kernel_main.cl:342-359) on the output */
+    CRT_RENDER_WRITE_RAYS  = 2,   /* materialise the RayGen buffer (kernel_main.cl:277-287) in HBM */
+    CRT_RENDER_ASYNC       = 4,   /* do not wait for completion (the reference always clFinish()es) */
+    CRT_RENDER_COUNTERS    = 8    /* instrumented launch that fills the work counters (slower) */
+};
+
+/* Device work counters of the last CRT_RENDER_COUNTERS / crt_query_hits launch. Same meaning as
+ * the oracle's OrcStats so tests can require exact equality. */
+typedef struct CrtCounters {
+    uint64_t rays, primary, secondary, hits, misses;
+    uint64_t traversals, pops, innerVisits, triTests, capHits, stackOverflows, maxStack;
+} CrtCounters;
+
+/* Renderer.cpp:122-193 (InitializeOpenCL + buffer creation) and ResourceManager.cpp:145-178
+ * (device pools, default white/black texels). `device` is the HIP ordinal this process owns.
+ * Allocates every pool at its reference capacity once; nothing is resized later except by
+ * crt_resize. */
+int crt_init(int device, int width, int height);
+/* Renderer.cpp:377-394, ResourceManager.cpp:303-319 */
+int crt_shutdown(void);
+/* Renderer.cpp:198-211: ignores sizes below 16 like the reference (returns CRT_OK, no change). */
+int crt_resize(int width, int height);
+/* Multi-GPU image tiling (no reference counterpart: upstream is single-device). The frame is cut
+ * into horizontal bands of `bandRows` rows (multiple of 16); this process renders bands
+ * rank, rank+nRanks, ... RayGen and Vignette still use full-frame coordinates. Default (16,0,1). */
+int crt_set_row_bands(int bandRows, int rank, int nRanks);
+
+/* ResourceManager.cpp:286 -- triangles in the 80-byte reference layout, offsets in bytes. */
+int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes);
+/* ResourceManager.cpp:293 -- BVH nodes (32 B each), offsets in bytes, indices as built on the host. */
+int crt_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes);
+/* ResourceManager.cpp:291 -- per-mesh root node indices (uint32). */
+int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count);
+/* ResourceManager.cpp:142,295 */
+int crt_upload_materials(const void* materials, size_t first, size_t count);
+/* ResourceManager.cpp:236 */
+int crt_upload_texture_table(const void* textures, size_t count);
+/* ResourceManager.cpp:177,203 -- packed RGB8 bytes at a byte offset into the texel pool. */
+int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes);
+/* Renderer.cpp:245,314 */
+int crt_upload_instances(const void* instances, size_t first, size_t count);
+
+/* Renderer.cpp:337-367: RayGen + Trace (+ PostProcess) for one frame, then (unless ASYNC) wait.
+ * invView / invProj are the camera's inverse matrices, row-major (hazard H10: taken as inputs). */
+int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags);
+int crt_sync(void);
+
+/* Closest-hit query for arbitrary world-space rays (host pointers, n rays) against the first
+ * `numInstances` instances: the instance loop + IntersectBVH of kernel_main.cl:198-217 exposed for
+ * hit-record parity tests. Also fills the work counters. */
+int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out);
+
+/* Output: the HDR float4 frame (the reference writes a CL-GL RGBA8 texture, Renderer.cpp:63,192). */
+int crt_read_output(float* dstRGBA, size_t floats);           /* full frame, width*height*4 floats */
+int crt_read_output_rows(float* dstRGBA, int row0, int rows); /* rows [row0,row0+rows) */
+int crt_read_rays(float* dst, size_t floats);                 /* width*height*3, after WRITE_RAYS */
+void* crt_output_device_ptr(void);
+int crt_owned_rows(void);                                     /* rows this rank renders per frame */
+
+/* Timing of the last crt_render measured with HIP events on the launch stream.
+ * which: 0 = whole frame, 1 = RayGen (only with WRITE_RAYS), 2 = Trace, 3 = PostProcess. */
+float crt_last_kernel_ms(int which);
+int crt_get_counters(CrtCounters* out);
+
+const char* crt_error_string(int code);
+const char* crt_device_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

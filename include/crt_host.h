@@ -1,0 +1,78 @@
+/* crt_host.h -- C linkage over the C++ host mirror (libcrt_host.so) so that non-C++ drivers
+ * (the Python tests, bench.py) can run the reference's own call sequence
+ * (Engine.cpp:56-80 start-up, EngineMain.cpp:11-17 per-frame) against
+ * Renderer:: / ResourceManager:: / AssetManager_ / CPU_RayCast. One thin forwarding function per
+ * mirrored C++ entry point; C++ callers should include the headers in clraytracer_amd/host/ directly.
+ */
+#ifndef CRT_HOST_H
+#define CRT_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#include "crt_types.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Renderer::Initialize (Renderer.cpp:175). Returns 1 on success, 0 on failure (crth_last_error). */
+int crth_initialize(int device, int width, int height);
+/* Host-only session: importer, BVH build and CPU_RayCast work; crth_render fails loudly. */
+int crth_initialize_host_only(int width, int height);
+void crth_terminate(void);                                   /* Renderer::Terminate */
+int crth_last_error(void);
+
+void crth_prepare_meshes(void);                              /* ResourceManager::PrepareMeshes */
+int crth_import_texture(const char* path);                   /* ResourceManager::ImportTexture */
+int crth_import_texture_rgb8(const char* name, int width, int height, const unsigned char* rgb);
+int crth_import_mesh(const char* path);                      /* ResourceManager::ImportMesh */
+void crth_push_meshes(void);                                 /* ResourceManager::PushMeshesToGPU */
+void crth_push_textures(void);                               /* ResourceManager::PushTexturesToGPU */
+void crth_push_materials(void);                              /* ResourceManager::PushMaterialsToGPU */
+int crth_create_material(int count);                         /* ResourceManager::CreateMaterial -> first handle, -1 on failure */
+void crth_edit_material(int handle, const CrtMaterial* value); /* ResourceManager::EditMaterial(handle) = *value */
+
+void crth_begin_instances(void);                             /* Renderer::BeginInstanceRegister */
+unsigned crth_register_instance(int mesh, int material, const float matrix[16]); /* material 0xFFFF = DefaultMaterial */
+void crth_end_instances(void);                               /* Renderer::EndInstanceRegister */
+void crth_clear_instances(void);
+void crth_set_mesh_matrix(unsigned instance, const float matrix[16]);
+void crth_set_mesh_position(unsigned instance, const float position[3]);
+void crth_set_instance_material(unsigned instance, int material);
+
+void crth_set_camera(const float position[3], const float front[3]); /* Camera position/Front + RecalculateView */
+void crth_get_camera(float invView[16], float invProj[16], float position[3]);
+void crth_resize(int width, int height);                     /* Renderer::OnWindowResize */
+void crth_set_postprocess(int enabled);
+void crth_set_row_bands(int bandRows, int rank, int nRanks);
+unsigned crth_render(float sunAngle);                        /* Renderer::Render: frame index, 0 on failure */
+const float* crth_map_output(void);                          /* Renderer::MapOutput */
+float crth_last_frame_ms(void);
+
+/* CPU_RayCast (CPURayTrace.cpp:186) over n rays (xyz triples). */
+void crth_cpu_raycast(const float* origins, const float* dirs, int n, CrtHitRecord* out, int nthreads);
+
+/* read-only views of the host arenas (ResourceManager.cpp:49-55, Renderer.cpp:45-50) */
+const CrtTri* crth_triangles(void);         size_t crth_num_triangles(void);
+const CrtBVHNode* crth_nodes(void);         size_t crth_num_nodes(void);
+const uint32_t* crth_roots(void);           int crth_num_meshes(void);
+const CrtMaterial* crth_materials(void);    int crth_num_materials(void);
+const CrtTexture* crth_textures(void);      int crth_num_textures(void);
+const CrtRGB8* crth_texels(void);           size_t crth_texel_bytes(void);
+const CrtMeshInstance* crth_instances(void); unsigned crth_num_instances(void);
+void crth_mesh_info(int mesh, uint32_t out[4]); /* numTriangles, triangleStart, materialStart, numMaterials */
+
+/* stand-alone pieces for known-answer tests */
+uint32_t crth_build_bvh(CrtTri* tris, const uint32_t* meshTriCounts, int numMeshes, CrtBVHNode* nodes, uint32_t* roots);
+uint16_t crth_float_to_half(float v);
+float crth_half_to_float(uint16_t h);
+void crth_inverse_transform(const float in[16], float out[16]);
+void crth_inverse(const float in[16], float out[16]);
+void crth_perspective_fov_rh(float fovRad, float width, float height, float zNear, float zFar, float out[16]);
+void crth_look_at_rh(const float eye[3], const float front[3], const float up[3], float out[16]);
+int crth_write_obj(const char* path, const float* positions, int numPositions, const float* uvs, int numUvs,
+                   const float* normals, int numNormals, const int* faces, const int* faceMaterial, int numFaces,
+                   const char* const* materialNames, int numMaterials);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
