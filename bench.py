@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the HIP ray-trace path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One *step* = one frame through the hot path: crt_render (RayGen fused into Trace, both bounces,
+wait for completion -- the reference's Render()+clFinish, Renderer.cpp:305-367) on a scene that is
+already resident in HBM. Workload:
+  N == 1 : BASELINE config 4 -- `multi-1M` (8 meshes, 1,000,960 triangles, 16 instances, textures),
+           1920x1080, primary + one reflection bounce.
+  N  > 1 : BASELINE config 5 -- the same scene at 3840x2160, the frame cut into 16-row bands dealt
+           round-robin to the ranks (replicated scene, no data-path collective); total work is fixed
+           as N grows ("scaling": "strong"). torch.distributed (RCCL) is only used for the barrier
+           and the MAX-over-ranks of the wall time.
+Rays = primary rays + secondary rays actually traced, counted on the device by an instrumented
+launch outside the timed region (and checked against the oracle in tests/).
+
+The JSON line also carries
+  roofline     : algorithmic HBM bytes of the dominant kernel (crt_trace_kernel) per launch
+                 (64 B x inner visits + 48 B x triangle tests + 80 B x instance records
+                 + fixed per-hit / per-miss / per-pixel bytes) / its mean HIP-event duration, vs 8 TB/s.
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference kernels) tracing one full frame of
+                 the same workload on this box's host cores (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def algorithmic_bytes(c, pixels):
+    """SURVEY.md 8d, layout-independent bytes from the work counters of one frame."""
+    per_ray = 64 * c["innerVisits"] + 48 * c["triTests"] + 80 * c["traversals"]
+    per_hit = (80 + 16 + 80 + 2 * 16 + 2 * 3) * c["hits"]
+    per_miss = (16 + 3) * c["misses"]
+    per_pixel = 16 * pixels  # float4 output write; RayGen is fused, so no 12 B ray write + read
+    return per_ray + per_hit + per_miss + per_pixel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="multi-1M")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n:
+        if world == 1 and n > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        n = world
+
+    import numpy as np
+    import torch
+    from clraytracer_amd import _lib, driver, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-trace path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if n > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    width = args.width or (1920 if n == 1 else 3840)
+    height = args.height or (1080 if n == 1 else 2160)
+    # scene files are generated once (rank 0) into the shared cache directory
+    if rank == 0:
+        sc = scenes.get(args.scene)
+    if dist is not None:
+        dist.barrier()
+    if rank != 0:
+        sc = scenes.get(args.scene)
+
+    t_load = time.time()
+    s = driver.Session(width, height, device=local_rank)
+    s.load_scene(sc)
+    s.set_row_bands(args.band_rows, rank, n)
+    t_load = time.time() - t_load
+
+    # instrumented launch (untimed): rays and work counters of this rank's share of the frame
+    s.render_raw(8)
+    cnt = s.counters()
+    own_rows = s.owned_rows()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        s.render_raw(0)
+    trace_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.render_raw(0)                      # synchronous: returns when the frame is complete
+        trace_ms.append(s.kernel_ms(2))      # HIP events around crt_trace_kernel on its launch stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    keys = ["rays", "primary", "secondary", "hits", "misses", "traversals", "pops", "innerVisits", "triTests"]
+    vec = torch.tensor([float(cnt[k]) for k in keys] + [float(own_rows * width), float(algorithmic_bytes(cnt, own_rows * width))],
+                       dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed, float(np.mean(trace_ms))], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = dict(zip(keys + ["pixels", "alg_bytes"], vec.tolist()))
+    elapsed_max, kernel_ms_max = tmax.tolist()
+
+    if rank == 0:
+        rays_per_frame = tot["rays"]
+        ms_per_step = elapsed_max * 1e3 / args.steps
+        value = rays_per_frame * args.steps / elapsed_max / 1e6
+        # roofline of the dominant kernel on this rank (per launch = this rank's share of one frame)
+        my_bytes = algorithmic_bytes(cnt, own_rows * width)
+        my_ms = float(np.mean(trace_ms))
+        achieved = my_bytes / (my_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{sc.name}: {sc.num_tris} triangles, {len(sc.meshes)} meshes, {len(sc.instances)} instances, "
+                                   f"{width}x{height}, primary + 1 reflection bounce, RayGen fused",
+                       "scene": sc.name, "width": width, "height": height, "rays_per_frame": int(rays_per_frame),
+                       "primary": int(tot["primary"]), "secondary": int(tot["secondary"]),
+                       "tiling": f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
+                       "device": _lib.hip().crt_device_name().decode(), "scene_load_s": round(t_load, 2)},
+            "kernel_ms": {"crt_trace_kernel_mean": round(my_ms, 4), "crt_trace_kernel_min": round(float(np.min(trace_ms)), 4),
+                          "max_over_ranks_mean": round(kernel_ms_max, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "crt_trace_kernel<false>", "algorithmic_bytes_per_launch": int(my_bytes),
+                         "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
+                         "inner_visits_per_ray": round(cnt["innerVisits"] / max(1, cnt["rays"]), 2),
+                         "tri_tests_per_ray": round(cnt["triTests"] / max(1, cnt["rays"]), 2)},
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            orc = oracle_lib.Oracle(s.arenas(), nthreads=threads)
+            iv, ip, pos = s.camera()
+            rays = orc.raygen(width, height, iv, ip)
+            t0 = time.perf_counter()
+            _, st = orc.trace(rays, pos, sc.sun_angle)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                                   "sample": f"one full {width}x{height} frame of the same scene ({st['rays']} rays, {dt:.2f} s wall)",
+                                   "rays_match_gpu": bool(st["rays"] == cnt["rays"])}
+        print(json.dumps(out), flush=True)
+
+    s.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

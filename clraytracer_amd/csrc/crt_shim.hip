@@ -301,8 +301,8 @@ void fill_scene(CrtDevScene& S, uint32_t numInstances)
 
 int alloc_frame_buffers(int w, int h)
 {
-    if (g.rays) { hipFree(g.rays); g.rays = nullptr; }
-    if (g.out) { hipFree(g.out); g.out = nullptr; }
+    if (g.rays) { (void)hipFree(g.rays); g.rays = nullptr; }
+    if (g.out) { (void)hipFree(g.out); g.out = nullptr; }
     HIPCHK(hipMalloc(&g.rays, sizeof(float) * 3 * (size_t)w * (size_t)h));
     HIPCHK(hipMalloc(&g.out, sizeof(float4) * (size_t)w * (size_t)h));
     HIPCHK(hipMemsetAsync(g.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
@@ -423,12 +423,12 @@ int crt_init(int device, int width, int height)
 int crt_shutdown(void)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    hipStreamSynchronize(g.stream);
+    (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.instances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf };
-    for (void* p : ptrs) if (p) hipFree(p);
-    for (int i = 0; i < 5; ++i) if (g.ev[i]) hipEventDestroy(g.ev[i]);
-    if (g.stream) hipStreamDestroy(g.stream);
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
     g = State();
     return CRT_OK;
 }
@@ -447,6 +447,12 @@ int crt_set_row_bands(int bandRows, int rank, int nRanks)
     if (bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
     g.bandRows = bandRows; g.rank = rank; g.nRanks = nRanks;
     return CRT_OK;
+}
+
+int crt_row_owner(int row, int bandRows, int nRanks)
+{
+    if (row < 0 || bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1) return CRT_E_BAD_ARGUMENT;
+    return (row / bandRows) % nRanks;
 }
 
 int crt_owned_rows(void)
@@ -605,7 +611,7 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     if (rc) return rc;
     const size_t rayBytes = sizeof(float) * 3 * (size_t)n, need = rayBytes * 2 + sizeof(CrtRayHit) * (size_t)n;
     if (need > g.queryBytes) {
-        if (g.queryBuf) hipFree(g.queryBuf);
+        if (g.queryBuf) (void)hipFree(g.queryBuf);
         g.queryBuf = nullptr; g.queryBytes = 0;
         HIPCHK(hipMalloc(&g.queryBuf, need));
         g.queryBytes = need;

@@ -63,6 +63,8 @@ int crt_resize(int width, int height);
  * into horizontal bands of `bandRows` rows (multiple of 16); this process renders bands
  * rank, rank+nRanks, ... RayGen and Vignette still use full-frame coordinates. Default (16,0,1). */
 int crt_set_row_bands(int bandRows, int rank, int nRanks);
+/* Which rank renders frame row `row` under that tiling (pure function, needs no device). */
+int crt_row_owner(int row, int bandRows, int nRanks);
 
 /* ResourceManager.cpp:286 -- triangles in the 80-byte reference layout, offsets in bytes. */
 int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes);
