@@ -50,8 +50,8 @@ struct CrtFrame {
     float lightY, lightZ;     // (float)sin((double)sunAngle), (float)cos((double)sunAngle), computed on the host
     int width, height;
     int tilesX;               // ceil(width / 16)
-    int numTiles;             // tilesX * owned tile rows
-    int chunk;                // ceil(numTiles / 8): tiles per XCD slab
+    int ownedTileRows;        // 16-row tile rows this rank renders
+    int gridBlocks;           // ceil(ownedTileRows / 8) * 8 * tilesX
     int tileRowsPerBand;      // bandRows / 16
     int rank, nRanks;
 };

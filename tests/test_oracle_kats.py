@@ -51,18 +51,24 @@ def test_triangle_edges_inclusive():
     assert tri_test((0.75, 0.5, 1), (0, 0, -1), X, Y, Z)[0] == 0
 
 
-def test_triangle_parallel_ray_nan_path():
-    # a == 0 -> f = inf (no epsilon test, kernel_main.cl:90): t = inf*0 = NaN, every comparison false
-    # -> passed == 1 and NaN is stored (hazard H4)
+def test_triangle_in_plane_ray_passes_with_nan():
+    # ray inside the triangle's plane: a == 0 -> f = inf (no epsilon test, kernel_main.cl:90) and every dot
+    # product is 0, so u = v = t = inf*0 = NaN; every comparison is false -> passed == 1, NaN stored (hazard H4)
+    p, tuv, idx = tri_test((0.25, 0.25, 0), (1, 0, 0), X, Y, Z)
+    assert p == 1 and idx == 3 and np.all(np.isnan(tuv))
+
+
+def test_triangle_parallel_ray_poisons_t_through_the_blend():
+    # parallel ray off the plane: t = u = +inf -> rejected, but the arithmetic blend (kernel_main.cl:101-104)
+    # computes inf*0 + 1*old = NaN: the running best t becomes NaN although nothing was hit
     p, tuv, idx = tri_test((0.25, 0.25, 1), (1, 0, 0), X, Y, Z)
-    assert p == 1 and idx == 3 and np.isnan(tuv[0])
-
-
-def test_triangle_blend_poisons_t_when_rejected_with_inf():
-    # parallel ray off the plane: u = +-inf, rejected, but the arithmetic blend computes inf*0 -> NaN
-    p, tuv, idx = tri_test((0.25, 5.0, 1), (1, 0, 0), X, Y, (0, 1, 0.5))
-    if p == 0:
-        assert np.isnan(tuv[0]) or tuv[0] == np.float32(99999.0)
+    assert p == 0 and idx == 7 and np.all(np.isnan(tuv))
+    # with a NaN best-t the XOR term is (t>0)^0: triangles *behind* the origin now pass, the index
+    # follows them, and t stays NaN for good (t*1 + 0*NaN)
+    p2, tuv2, idx2 = tri_test((0.25, 0.25, -1), (0, 0, -1), X, Y, Z, t0=float("nan"))
+    assert p2 == 1 and idx2 == 3 and np.isnan(tuv2[0])
+    p3, tuv3, idx3 = tri_test((0.25, 0.25, 1), (0, 0, -1), X, Y, Z, t0=float("nan"))
+    assert p3 == 0 and idx3 == 7            # a proper front hit is now rejected
 
 
 def aabb(o, d, bmin, bmax, best=99999.0):
@@ -185,7 +191,7 @@ def test_sampling_helpers():
     d = np.array([0, 0, -1], np.float32)                                   # atan2pi(0,1) = 0, acospi(0) = .5
     assert L.orc_sample_skybox(f32(d)[0], t) == 2 * 8 + 0 + 2
     d = np.array([0, 1, 0], np.float32)
-    assert L.orc_sample_skybox(f32(d)[0], t) == 2                          # phi = 0
+    assert L.orc_sample_skybox(f32(d)[0], t) == 0 * 8 + 4 + 2              # phi = 0; atan2(+0, -0.0) = pi -> theta = 4
     d = np.array([-1, 0, 0], np.float32)                                   # atan2pi(-1, -0) = -0.5 -> theta = -2
     assert L.orc_sample_skybox(f32(d)[0], t) == 2 * 8 - 2 + 2
     out = np.zeros(3, np.float32)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Digest rocprofv3 CSV output (gpurun_out/prof_<tag>_*) into profiles/<tag>_summary.{md,json}.
+
+    python tools/profile_summary.py r01 [kernel-substring]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false>"
+    base = os.path.join(ROOT, "gpurun_out")
+    out = {"tag": tag, "kernel": kern, "kernel_stats": [], "counters": {}, "bench_line": None}
+    for f in glob.glob(os.path.join(base, f"prof_{tag}_stats", "*", "*_kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            out["kernel_stats"].append({"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                        "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])})
+    log = os.path.join(base, f"prof_{tag}_stats.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith('{"metric"'):
+                out["bench_line"] = json.loads(line)
+    meta = {}
+    for d in sorted(glob.glob(os.path.join(base, f"prof_{tag}_*"))):
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if kern in r["Kernel_Name"]:
+                    acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+            for k, v in acc.items():
+                out["counters"][k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+    out["dispatch"] = meta
+    c = {k: v["mean_per_launch"] for k, v in out["counters"].items()}
+    d = {}
+    if "FETCH_SIZE" in c:
+        d["hbm_read_MB_raw_FETCH_SIZE"] = c["FETCH_SIZE"] / 1024.0
+        d["hbm_read_MB_x2_gfx950_correction"] = 2 * c["FETCH_SIZE"] / 1024.0
+    if "WRITE_SIZE" in c:
+        d["hbm_write_MB"] = c["WRITE_SIZE"] / 1024.0
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+        d["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / max(1.0, c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if "SQ_WAVE_CYCLES" in c and "SQ_WAVES" in c:
+        d["wave_quad_cycles_per_wave"] = c["SQ_WAVE_CYCLES"] / max(1.0, c["SQ_WAVES"])
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        d["wave_parked_fraction"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+        d["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    out["derived"] = d
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
+    with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
+        f.write(f"# rocprofv3 summary `{tag}` (MI355X, `python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline`)\n\n")
+        if out["bench_line"]:
+            b = out["bench_line"]
+            f.write(f"bench line under the profiler: {b['value']} {b['unit']}, {b['ms_per_step']} ms/frame, workload `{b['config']['workload']}`\n\n")
+        f.write("## --kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+        for k in sorted(out["kernel_stats"], key=lambda r: -r["pct"]):
+            f.write(f"| `{k['name'][:90]}` | {k['calls']} | {k['avg_ns'] / 1e3:.1f} | {k['min_ns'] / 1e3:.1f} | {k['max_ns'] / 1e3:.1f} | {k['pct']:.2f} |\n")
+        f.write(f"\n## PMC passes (mean per launch of `{kern}`; one counter group per run, 5-step runs)\n\ndispatch: {meta}\n\n| counter | mean per launch | launches |\n|---|---|---|\n")
+        for k in sorted(out["counters"]):
+            f.write(f"| {k} | {out['counters'][k]['mean_per_launch']:.4g} | {out['counters'][k]['launches']} |\n")
+        f.write("\n## derived\n\n")
+        for k, v in d.items():
+            f.write(f"- {k}: {v:.4g}\n")
+        f.write("\nFETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x "
+                "(MI355X_MICROARCH.md, HBM section), so both the raw and the doubled figure are listed. SQ_* cycle counters are in quad-cycles.\n")
+    print(json.dumps(d, indent=1))
+
+
+if __name__ == "__main__":
+    main()
