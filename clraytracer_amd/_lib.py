@@ -74,6 +74,7 @@ HIP_API = {
     "crt_owned_rows": (C.c_int, []),
     "crt_last_kernel_ms": (C.c_float, [C.c_int]),
     "crt_get_counters": (C.c_int, [C.POINTER(CrtCounters)]),
+    "crt_debug_read_stamps": (C.c_int, [_vp, _sz, C.POINTER(C.c_size_t)]),
     "crt_error_string": (C.c_char_p, [C.c_int]),
     "crt_device_name": (C.c_char_p, []),
 }

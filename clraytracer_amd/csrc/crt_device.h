@@ -19,6 +19,12 @@
 //   triCold : the 32-byte attribute tail of the reference Tri (uv halfs, material, normal halfs),
 //             read once per shaded hit.
 //   texels  : RGBA8 (one dword per texel) expanded from the packed RGB8 pool.
+//   instBounds : per instance, a conservative world-space bounding sphere of the mesh's root box
+//             (computed in double on the host at upload time). Upstream has no TLAS: every ray
+//             transforms into every instance and tests the root's two child boxes
+//             (kernel_main.cl:198-217). A ray that misses the enlarged sphere cannot pass either
+//             slab test, so the instance is skipped with identical results -- and the counters
+//             record the one pop / one inner visit upstream would have spent on it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -36,6 +42,7 @@ struct CrtDevScene {
     const uint32_t* __restrict__ bigLeaf;
     const uint32_t* __restrict__ rootRefs;
     const CrtMeshInstance* __restrict__ instances;
+    const float4* __restrict__ instBounds;   // world-space bounding sphere per instance (xyz, r); r < 0: never cull
     const CrtMaterial* __restrict__ materials;
     const CrtTexture* __restrict__ textures;
     const uint32_t* __restrict__ texels;
@@ -212,7 +219,18 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
     Closest c;
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
     c.hit.t = 0.0f; c.hit.u = 0.0f; c.hit.v = 0.0f; c.hit.tri = 0;
+    const float dd = dot3(d, d);
     for (uint32_t i = 0; i < S.numInstances; ++i) {
+        // conservative sphere cull (written so that any NaN makes every comparison false -> no cull)
+        const float4 bs = S.instBounds[i];                    // uniform index -> scalar load
+        const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);
+        const float oc2 = dot3(oc, oc), b = dot3(oc, d);
+        const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2; // 1 % on the radius + slack growing with distance
+        const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
+        if (cull) {
+            if (COUNT) { lc.traversals++; lc.pops++; lc.innerVisits++; }
+            continue;
+        }
         Triout triout;
         triout.t = c.distance; triout.tri = 0; triout.u = 0.0f; triout.v = 0.0f;
         const CrtMeshInstance* inst = S.instances + i;       // uniform index -> scalar loads

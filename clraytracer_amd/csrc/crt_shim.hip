@@ -73,13 +73,17 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py)
 // kernel Trace (kernel_main.cl:164-275) with RayGen (kernel_main.cl:277-287) fused: the ray
 // direction is computed with the same arithmetic RayGen stores, so the 24.9 MB ray buffer
 // round-trip disappears. One thread per pixel, both bounces.
-template <bool COUNT>
+// STAMP (diagnostic build only, CRT_RENDER_STAMPS): every wave records start/end s_memrealtime (100 MHz),
+// its s_memtime cycle count and XCC/HW ids into a buffer nothing else reads.
+template <bool COUNT, bool STAMP = false>
 __global__ __launch_bounds__(CRT_BLOCK) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                               unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
     uint32_t* stack = s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
+    unsigned long long t0rt = 0, t0c = 0;
+    if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
     int px, py;
     const bool active = lane_pixel(F, px, py);
     if (active) {
@@ -100,6 +104,14 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_trace_kernel(CrtDevScene S, Crt
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
     }
     if (COUNT) flush_counters(lc, counters);
+    if (STAMP) {
+        const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1rt = __builtin_amdgcn_s_memrealtime();
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* st = counters + 16 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+            st[0] = t0rt; st[1] = t1rt; st[2] = t1c - t0c;
+            st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+        }
+    }
 }
 
 // kernel RayGen as its own launch (only for CRT_RENDER_WRITE_RAYS)
@@ -253,8 +265,11 @@ struct State {
     float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
     uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr;
     CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
+    float4* instBounds = nullptr;
+    CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
     float* rays = nullptr; float4* out = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
+    unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
     uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
@@ -298,7 +313,7 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
 void fill_scene(CrtDevScene& S, uint32_t numInstances)
 {
     S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs;
-    S.instances = g.instances; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
+    S.instances = g.instances; S.instBounds = g.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
     S.numTexels = (int)((g.texelBytesHigh + 2) / 3);
     if (S.numTexels < 1) S.numTexels = 1;
     S.numInstances = numInstances;
@@ -316,6 +331,8 @@ int alloc_frame_buffers(int w, int h)
     return CRT_OK;
 }
 
+int rebuild_instance_bounds();
+
 int rebuild_bvh_layout()
 {
     HIPCHK(hipMemsetAsync(g.err, 0, sizeof(int), g.stream));
@@ -331,7 +348,71 @@ int rebuild_bvh_layout()
     HIPCHK(hipMemcpyAsync(&err, g.err, sizeof(int), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     g.sceneValid = (err == 0);
-    return err ? CRT_E_BAD_ARGUMENT : CRT_OK;
+    if (err) return CRT_E_BAD_ARGUMENT;
+    return rebuild_instance_bounds();
+}
+
+// World-space bounding spheres for the conservative instance cull (crt_device.h). Runs at upload
+// time only. forward = inverse(inverseTransform) in double; sphere = image of the root box's corners.
+bool invert4(const double m[16], double out[16])
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = m[r * 4 + c]; a[r][4 + c] = (r == c) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        if (!(fabs(a[piv][col]) > 1e-300)) return false;
+        if (piv != col) for (int c = 0; c < 8; ++c) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+        const double inv = 1.0 / a[col][col];
+        for (int c = 0; c < 8; ++c) a[col][c] *= inv;
+        for (int r = 0; r < 4; ++r) if (r != col) { const double f = a[r][col]; if (f != 0.0) for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c]; }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) out[r * 4 + c] = a[r][4 + c];
+    return true;
+}
+
+int rebuild_instance_bounds()
+{
+    static float4 bounds[CRT_MAX_INSTANCES];
+    static CrtBVHNode rootNodes[CRT_MAX_MESHES];
+    static bool haveRoot[CRT_MAX_MESHES];
+    for (uint32_t m = 0; m < CRT_MAX_MESHES; ++m) {
+        haveRoot[m] = m < g.numRoots && g.hRoots[m] < g.nodeCount;
+        if (haveRoot[m]) HIPCHK(hipMemcpyAsync(&rootNodes[m], g.rawNodes + g.hRoots[m], sizeof(CrtBVHNode), hipMemcpyDeviceToHost, g.stream));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (uint32_t i = 0; i < CRT_MAX_INSTANCES; ++i) {
+        bounds[i] = make_float4(0.f, 0.f, 0.f, -1.0f);
+        if (i >= g.instHigh) continue;
+        const CrtMeshInstance& inst = g.hInstances[i];
+        if (inst.meshIndex >= CRT_MAX_MESHES || !haveRoot[inst.meshIndex]) continue;
+        const CrtBVHNode& root = rootNodes[inst.meshIndex];
+        if (root.triCount > 0) continue;      // single-leaf mesh: its triangles are tested without any box test (hazard H3)
+        double inv[16], fwd[16];
+        for (int k = 0; k < 16; ++k) inv[k] = (double)(&inst.inverseTransform.m[0][0])[k];
+        if (!invert4(inv, fwd)) continue;
+        auto xform = [&](double x, double y, double z, double* o) {
+            for (int c = 0; c < 3; ++c) o[c] = x * fwd[0 + c] + y * fwd[4 + c] + z * fwd[8 + c] + fwd[12 + c];
+        };
+        const double lo[3] = { root.aabbMin[0], root.aabbMin[1], root.aabbMin[2] }, hi[3] = { root.aabbMax[0], root.aabbMax[1], root.aabbMax[2] };
+        double cw[3];
+        xform(0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]), cw);
+        double r = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            double p[3];
+            xform((k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2], p);
+            const double dx = p[0] - cw[0], dy = p[1] - cw[1], dz = p[2] - cw[2];
+            const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+            if (dist > r) r = dist;
+        }
+        const float rf = (float)(r * (1.0 + 1e-4)) ;
+        const float4 b = make_float4((float)cw[0], (float)cw[1], (float)cw[2], rf);
+        if (!(isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w)) || !(b.w < 1e18f)) continue;
+        bounds[i] = b;
+    }
+    HIPCHK(hipMemcpyAsync(g.instBounds, bounds, sizeof bounds, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
 }
 
 int collect_timing()
@@ -405,6 +486,7 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.rootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
+    HIPCHK(hipMalloc(&g.instBounds, CRT_MAX_INSTANCES * sizeof(float4)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMalloc(&g.counters, 12 * sizeof(unsigned long long)));
@@ -415,7 +497,9 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMemset(g.materials, 0, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMemset(g.textures, 0, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMemset(g.texels, 0, 64));
-    g.nodeCount = 0; g.numRoots = 0; g.texelBytesHigh = 0; g.trisHigh = 0; g.sceneValid = true;
+    g.nodeCount = 0; g.numRoots = 0; g.texelBytesHigh = 0; g.trisHigh = 0; g.sceneValid = true; g.instHigh = 0;
+    memset(g.hInstances, 0, sizeof g.hInstances); memset(g.hRoots, 0, sizeof g.hRoots);
+    { int rcb = rebuild_instance_bounds(); if (rcb) return rcb; }
     g.bandRows = 16; g.rank = 0; g.nRanks = 1;
     int rc = alloc_frame_buffers(width, height);
     if (rc) return rc;
@@ -430,7 +514,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf };
+                     g.texels, g.instances, g.instBounds, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -503,6 +587,7 @@ int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count)
     if (!roots) return CRT_E_BAD_ARGUMENT;
     if (firstMesh + count > CRT_MAX_MESHES) return CRT_E_OUT_OF_RANGE;
     HIPCHK(hipMemcpyAsync(g.roots + firstMesh, roots, count * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+    memcpy(g.hRoots + firstMesh, roots, count * sizeof(uint32_t));
     if (firstMesh + count > g.numRoots) g.numRoots = (uint32_t)(firstMesh + count);
     return rebuild_bvh_layout();
 }
@@ -558,7 +643,9 @@ int crt_upload_instances(const void* instances, size_t first, size_t count)
     for (size_t i = 0; i < count; ++i) if (in[i].meshIndex >= CRT_MAX_MESHES) return CRT_E_BAD_ARGUMENT;
     HIPCHK(hipMemcpyAsync(g.instances + first, instances, count * sizeof(CrtMeshInstance), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    return CRT_OK;
+    memcpy(g.hInstances + first, instances, count * sizeof(CrtMeshInstance));
+    if (first + count > g.instHigh) g.instHigh = (uint32_t)(first + count);
+    return rebuild_instance_bounds();
 }
 
 int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags)
@@ -580,7 +667,18 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(g.ev[1], g.stream));
-    if (flags & CRT_RENDER_COUNTERS) {
+    if (flags & CRT_RENDER_STAMPS) {
+        const size_t need = (16 + (size_t)grid * 16) * sizeof(unsigned long long);
+        if (need > g.stampBytes) {
+            if (g.stamps) (void)hipFree(g.stamps);
+            g.stamps = nullptr; g.stampBytes = 0;
+            HIPCHK(hipMalloc(&g.stamps, need));
+            g.stampBytes = need;
+        }
+        g.stampWaves = (size_t)grid * 4;
+        HIPCHK(hipMemsetAsync(g.stamps, 0, need, g.stream));
+        crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
+    } else if (flags & CRT_RENDER_COUNTERS) {
         HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
         crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
     } else {
@@ -674,6 +772,18 @@ float crt_last_kernel_ms(int which)
     if (!g.initialized || which < 0 || which > 3) return -1.0f;
     if (collect_timing() != CRT_OK) return -1.0f;
     return g.ms[which];
+}
+
+int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!numWaves) return CRT_E_BAD_ARGUMENT;
+    *numWaves = g.stampWaves;
+    if (!dst || !g.stamps) return CRT_OK;
+    const size_t n = maxWaves < g.stampWaves ? maxWaves : g.stampWaves;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(dst, g.stamps + 16, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return CRT_OK;
 }
 
 int crt_get_counters(CrtCounters* out)

@@ -40,7 +40,8 @@ enum {
     CRT_RENDER_POSTPROCESS = 1,   /* also run PostProcess (kernel_main.cl:342-359) on the output */
     CRT_RENDER_WRITE_RAYS  = 2,   /* materialise the RayGen buffer (kernel_main.cl:277-287) in HBM */
     CRT_RENDER_ASYNC       = 4,   /* do not wait for completion (the reference always clFinish()es) */
-    CRT_RENDER_COUNTERS    = 8    /* instrumented launch that fills the work counters (slower) */
+    CRT_RENDER_COUNTERS    = 8,   /* instrumented launch that fills the work counters (slower) */
+    CRT_RENDER_STAMPS      = 16   /* diagnostic launch: per-wave start/end clock stamps (crt_debug_read_stamps) */
 };
 
 /* Device work counters of the last CRT_RENDER_COUNTERS / crt_query_hits launch. Same meaning as
@@ -102,6 +103,9 @@ int crt_owned_rows(void);                                     /* rows this rank 
  * which: 0 = whole frame, 1 = RayGen (only with WRITE_RAYS), 2 = Trace, 3 = PostProcess. */
 float crt_last_kernel_ms(int which);
 int crt_get_counters(CrtCounters* out);
+/* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 4 x uint64 {start, end (s_memrealtime, 100 MHz),
+ * shader cycles, XCC_ID | HW_ID << 32}. Pass dst = NULL to query the wave count. */
+int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves);
 
 const char* crt_error_string(int code);
 const char* crt_device_name(void);

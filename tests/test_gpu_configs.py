@@ -1,0 +1,70 @@
+"""BASELINE.json configs 2-5 on the GPU at their full sizes, against the CPU oracle.
+
+config 2: cornell-1k 1920x1080 | config 3: sponza-class-250k 1920x1080 | config 4: multi-1M 1920x1080
+config 5: multi-1M 3840x2160 rendered as 8 row-band ranks on one GPU, stitched, vs the single-rank frame.
+Tolerances as in test_gpu_parity.py (RMSE < 1e-4 pre-PostProcess; hit records and counters exact).
+"""
+import numpy as np
+import pytest
+
+from clraytracer_amd import _lib, driver, scenes
+import oracle_lib
+from util import bits, rmse, seeded_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["cornell-1k", "sponza-class-250k", "multi-1M"])
+def full(request, nthreads):
+    sc = scenes.get(request.param)
+    s = driver.Session(1920, 1080, device=0)
+    s.load_scene(sc)
+    orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+    yield sc, s, orc
+    s.close()
+
+
+def test_full_frame_1080p(full):
+    sc, s, orc = full
+    s.render_raw(8)
+    gpu = s.read_output()
+    cnt = s.counters()
+    iv, ip, pos = s.camera()
+    rays = orc.raygen(s.width, s.height, iv, ip)
+    ref, st = orc.trace(rays, pos, sc.sun_angle)
+    r = rmse(gpu, ref)
+    d = np.abs(gpu[..., :3].astype(np.float64) - ref[..., :3].astype(np.float64)).max(-1)
+    bad = int((d > 1e-5).sum())
+    print(f"{sc.name} 1920x1080: RMSE {r:.3e}; {bad} pixels differ by >1e-5 (max {d.max():.3e}); rays {st['rays']}, "
+          f"inner/ray {st['innerVisits'] / st['rays']:.2f}, tri/ray {st['triTests'] / st['rays']:.2f}, maxStack {st['maxStack']}, capHits {st['capHits']}")
+    assert r < 1e-4
+    assert bad <= int(1e-5 * d.size) + 1
+    assert cnt == st
+    assert st["stackOverflows"] == 0
+    s.render_raw(0)
+    assert np.array_equal(bits(s.read_output()), bits(gpu))
+
+
+def test_hit_records_65536_rays(full):
+    sc, s, orc = full
+    iv, ip, pos = s.camera()
+    a = s.arenas()
+    o, d = seeded_rays(a, pos, 65536, seed=77)
+    # plus rays that graze the instances' bounding volumes (exercise the conservative instance cull):
+    rng = np.random.RandomState(5)
+    k = rng.randint(0, len(a["instances"]), 16384)
+    fwd = np.linalg.inv(a["instances"]["inv"][k].astype(np.float64))
+    lo = a["tris"]["v0"].min(0).astype(np.float64); hi = a["tris"]["v0"].max(0).astype(np.float64)
+    c = np.einsum("ni,nij->nj", np.concatenate([np.tile((lo + hi) / 2, (len(k), 1)), np.ones((len(k), 1))], 1), fwd)[:, :3]
+    rad = np.linalg.norm(hi - lo) / 2 * np.abs(np.linalg.det(fwd[:, :3, :3])) ** (1 / 3)
+    og = c + rng.normal(size=(len(k), 3)) * rad[:, None] * 4
+    tgt = c + (lambda v: v / np.linalg.norm(v, axis=1, keepdims=True))(rng.normal(size=(len(k), 3))) * (rad * rng.uniform(0.7, 1.15, len(k)))[:, None]
+    dg = tgt - og; dg /= np.linalg.norm(dg, axis=1, keepdims=True)
+    o = np.concatenate([o, og.astype(np.float32)]); d = np.concatenate([d, dg.astype(np.float32)])
+    gpu = s.query_hits(o, d)
+    ref, st = orc.closest_hits(o, d)
+    assert (ref["instance"] >= 0).sum() > 5000
+    assert np.array_equal(gpu["instance"], ref["instance"]) and np.array_equal(gpu["tri"], ref["tri"])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(bits(gpu[f]), bits(ref[f])), f
+    assert s.counters() == st

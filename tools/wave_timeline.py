@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave start/end stamps of one crt_trace_kernel launch (run on the GPU box).
+    python tools/wave_timeline.py [scene] [width] [height]
+Prints the distribution of wave durations, residency over time and per-XCD busy spans."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clraytracer_amd import _lib, driver, scenes  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "multi-1M"
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
+with driver.Session(w, h, device=0) as s:
+    s.load_scene(scenes.get(name))
+    for _ in range(3):
+        s.render_raw(0)
+    s.render_raw(16)
+    n = C.c_size_t(0)
+    _lib.check(s.hip.crt_debug_read_stamps(None, 0, C.byref(n)))
+    st = np.zeros((n.value, 4), np.uint64)
+    _lib.check(s.hip.crt_debug_read_stamps(st.ctypes.data, n.value, C.byref(n)))
+    ms = s.kernel_ms(2)
+st = st[st[:, 1] > 0]
+t0 = st[:, 0].min()
+start = (st[:, 0] - t0).astype(np.float64) / 100.0     # us
+end = (st[:, 1] - t0).astype(np.float64) / 100.0
+dur = end - start
+xcc = (st[:, 3] & 0xF).astype(int)
+print(f"{name} {w}x{h}: kernel {ms * 1e3:.1f} us (events), {len(st)} waves stamped, span {end.max():.1f} us")
+print("wave duration us: mean %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
+print("shader cycles per wave: mean %.0f max %d ; clock ~ %.2f GHz" % (st[:, 2].mean(), st[:, 2].max(), np.median(st[:, 2].astype(np.float64) / np.maximum(dur, 1e-3)) / 1e3))
+edges = np.linspace(0, end.max(), 21)
+print("time slice (us) : resident waves (avg)   [capacity 256 CUs x 20 = 5120]")
+for a, b in zip(edges[:-1], edges[1:]):
+    ov = np.clip(np.minimum(end, b) - np.maximum(start, a), 0, None).sum() / (b - a)
+    print(f"  {a:7.1f}-{b:7.1f}: {ov:7.0f}")
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print(f"XCC {x}: {m.sum()} waves, first start {start[m].min():.1f}, last end {end[m].max():.1f}, sum dur {dur[m].sum() / 1e3:.1f} ms")
+top = np.argsort(-dur)[:8]
+print("slowest waves (us):", np.round(dur[top], 1), "start", np.round(start[top], 1))
