@@ -32,8 +32,9 @@
 #include "../../include/crt_types.h"
 
 #define CRT_LEAF_BIT 0x80000000u
-#define CRT_BLOCK 256
-#define CRT_TILE 16
+#define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
+#define CRT_WAVES_PER_SIMD 5   // 20 waves per CU is what the 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
+#define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 
 struct CrtDevScene {
     const float4* __restrict__ pairs;
@@ -42,6 +43,7 @@ struct CrtDevScene {
     const uint32_t* __restrict__ bigLeaf;
     const uint32_t* __restrict__ rootRefs;
     const CrtMeshInstance* __restrict__ instances;
+    const struct CrtDevInstance* __restrict__ devInstances;
     const float4* __restrict__ instBounds;   // world-space bounding sphere per instance (xyz, r); r < 0: never cull
     const CrtMaterial* __restrict__ materials;
     const CrtTexture* __restrict__ textures;
@@ -96,6 +98,7 @@ __device__ __forceinline__ int f2i(float x)
 }
 __device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__ushort_as_half((unsigned short)bits16)); }
 
+struct CrtDevInstance;
 struct Triout { float t, u, v; uint32_t tri; };
 
 struct LaneCounters {
@@ -137,57 +140,6 @@ __device__ __forceinline__ int intersect_triangle(v3 o, v3 d, const float* __res
     return passed;
 }
 
-// kernel_main.cl:124-160. `stack` points at this lane's column of the workgroup's LDS stack
-// (slot s lives at stack[s * CRT_BLOCK]): 32 slots x 4 B x 64 lanes = 8 KiB per wave, bank-conflict
-// free because consecutive lanes hit consecutive dwords.
-template <bool COUNT>
-__device__ __forceinline__ int intersect_bvh(const CrtDevScene& S, v3 o, v3 d, uint32_t rootRef, Triout& out,
-                                             uint32_t* stack, LaneCounters& lc)
-{
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    int sp = 1, protection = 0, intersection = 0;
-    stack[0] = rootRef;
-    if (COUNT) lc.traversals++;
-
-    while (sp > 0) {
-        if (!(protection++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; break; }
-        if (COUNT) lc.pops++;
-        --sp;
-        uint32_t ref = stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK];
-        for (;;) {
-            if (ref & CRT_LEAF_BIT) {
-                uint32_t first = ref & 0x00FFFFFFu;
-                uint32_t cnt = (ref >> 24) & 0x7Fu;
-                if (cnt == 0) cnt = S.bigLeaf[first];
-                for (uint32_t i = first, end = first + cnt; i < end; ++i) {
-                    if (COUNT) lc.triTests++;
-                    intersection |= intersect_triangle(o, d, S.triHot + (size_t)i * 9, out, i);
-                }
-                break;
-            }
-            const float4* p = S.pairs + (size_t)ref * 4;
-            const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
-            if (COUNT) lc.innerVisits++;
-            float dist1 = intersect_aabb(o, inv, lmin, lmax, out.t);
-            float dist2 = intersect_aabb(o, inv, rmin, rmax, out.t);
-            uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
-            if (dist1 > dist2) {
-                float tf = dist1; dist1 = dist2; dist2 = tf;
-                uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
-            }
-            if (dist1 == 1e30f) break;
-            ref = nearRef;
-            if (dist2 != 1e30f) {
-                if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
-                stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] = farRef;
-                sp++;
-                if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
-            }
-        }
-    }
-    return intersection;
-}
-
 // MathAndSTL.cl:100-102 with a row-major matrix in memory: ((m.x*v.x + m.y*v.y) + m.z*v.z) + m.w*v.w
 __device__ __forceinline__ v3 matmul_xyz(const float* __restrict__ m, float vx, float vy, float vz, float vw)
 {
@@ -212,38 +164,139 @@ __device__ __forceinline__ v3 mat3mul(const float* __restrict__ m, v3 v)
 
 struct Closest { float distance; int hitInstance; int anyHit; Triout hit; };
 
-// kernel_main.cl:198-217: every ray visits every instance (there is no TLAS upstream).
-template <bool COUNT>
+// diagnostic (ITERS builds only): true in exactly one active lane, so summing over lanes counts wave-level loop trips
+__device__ __forceinline__ bool first_active_lane() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
+
+// Device-side instance record (64 B, built at upload): the 3 used columns of inverseTransform
+// (MatMul(...).xyz and Mat3Mul never read column 3) with the root ref and materialStart in the
+// spare lanes. One aligned 64-byte gather per lane when a lane enters an instance.
+struct CrtDevInstance { float4 r0, r1, r2, r3; };   // rK = {m[K][0], m[K][1], m[K][2], extra}; r0.w = rootRef, r1.w = materialStart
+
+__device__ __forceinline__ v3 xform_xyz(const CrtDevInstance& m, float vx, float vy, float vz, float vw)
+{
+    v3 r;   // MathAndSTL.cl:100-102: ((m.x*v.x + m.y*v.y) + m.z*v.z) + m.w*v.w
+    r.x = ((m.r0.x * vx + m.r1.x * vy) + m.r2.x * vz) + m.r3.x * vw;
+    r.y = ((m.r0.y * vx + m.r1.y * vy) + m.r2.y * vz) + m.r3.y * vw;
+    r.z = ((m.r0.z * vx + m.r1.z * vy) + m.r2.z * vz) + m.r3.z * vw;
+    return r;
+}
+
+__device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
+{
+    v3 r;   // MathAndSTL.cl:104-106 on ConvertToMatrix3(inverseTransform)
+    r.x = (m.r0.x * v.x + m.r1.x * v.y) + m.r2.x * v.z;
+    r.y = (m.r0.y * v.x + m.r1.y * v.y) + m.r2.y * v.z;
+    r.z = (m.r0.z * v.x + m.r1.z * v.y) + m.r2.z * v.z;
+    return r;
+}
+
+// The instance loop + IntersectBVH of kernel_main.cl:124-160,198-217 as ONE per-lane state machine.
+//
+// Upstream (and a literal port) runs `for instance { traverse }` in lock-step: a wave pays, for every
+// instance, the slowest lane's traversal (sum over instances of max over lanes). Here every lane walks
+// its own ascending list of candidate instances and its own traversal; a lane that finishes an instance
+// moves on to its next candidate while its neighbours are still inside another one (max over lanes of
+// the per-lane sum). Per ray the sequence of instances, node visits, triangle tests and the running
+// best t are exactly upstream's, so results are bit-identical.
+//
+//  1. candidate mask: a wave-uniform pass over the instance bounds (scalar loads) sets bit k when the
+//     ray cannot be proven to miss instance k's bounding sphere (conservative; NaN -> candidate).
+//     A culled instance costs upstream exactly one pop and one inner visit and changes nothing,
+//     which is what the counters record for it.
+//  2. unified loop: [enter next candidate] -> [descend inner nodes] -> [leaf triangles, pop].
+// The traversal stack lives in LDS (32 slots x 64 lanes x 4 B = 8 KiB per wave; slot s of this lane at
+// stack[s * 64], conflict-free); slot indices wrap modulo 32 where upstream would overflow its array.
+template <bool COUNT, bool ITERS = false>
 __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, uint32_t* stack, LaneCounters& lc)
 {
     Closest c;
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
     c.hit.t = 0.0f; c.hit.u = 0.0f; c.hit.v = 0.0f; c.hit.tri = 0;
     const float dd = dot3(d, d);
-    for (uint32_t i = 0; i < S.numInstances; ++i) {
-        // conservative sphere cull (written so that any NaN makes every comparison false -> no cull)
-        const float4 bs = S.instBounds[i];                    // uniform index -> scalar load
-        const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);
-        const float oc2 = dot3(oc, oc), b = dot3(oc, d);
-        const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2; // 1 % on the radius + slack growing with distance
-        const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
-        if (cull) {
-            if (COUNT) { lc.traversals++; lc.pops++; lc.innerVisits++; }
-            continue;
+
+    for (uint32_t base = 0; base < S.numInstances; base += 64) {
+        const uint32_t cnt = (S.numInstances - base) < 64u ? (S.numInstances - base) : 64u;
+        unsigned long long cand = 0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4 bs = S.instBounds[base + k];                 // uniform index -> scalar load
+            const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);
+            const float oc2 = dot3(oc, oc), b = dot3(oc, d);
+            const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2;     // 1 % on the radius + slack growing with distance
+            const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
+            if (!cull) cand |= 1ull << k;
         }
-        Triout triout;
-        triout.t = c.distance; triout.tri = 0; triout.u = 0.0f; triout.v = 0.0f;
-        const CrtMeshInstance* inst = S.instances + i;       // uniform index -> scalar loads
-        const float* m = &inst->inverseTransform.m[0][0];
-        v3 mo = matmul_xyz(m, o.x, o.y, o.z, 1.0f);
-        v3 md = matmul_xyz(m, d.x, d.y, d.z, 0.0f);
-        uint32_t rootRef = S.rootRefs[inst->meshIndex];
-        if (intersect_bvh<COUNT>(S, mo, md, rootRef, triout, stack, lc)) {
-            c.hitInstance = (int)i;
-            c.hit = triout;
-            c.distance = triout.t;
-            c.anyHit = 1;
+        if (COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(cand); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
+
+        bool active = false;
+        v3 mo = mk3(0.f, 0.f, 0.f), md = mo, inv = mo;
+        Triout tr; tr.t = 0.f; tr.u = 0.f; tr.v = 0.f; tr.tri = 0;
+        int sp = 0, prot = 0, inters = 0;
+        uint32_t ref = 0, curInst = 0;
+
+        // ends the current traversal: keep the hit if any triangle passed (kernel_main.cl:210-216)
+#define CRT_FINISH() do { if (inters) { c.hitInstance = (int)curInst; c.hit = tr; c.distance = tr.t; c.anyHit = 1; } active = false; } while (0)
+        // `while (currentNodeIndex > 0 && protection++ < 250) node = stack[--currentNodeIndex]` (kernel_main.cl:131-133)
+#define CRT_POP_NEXT() do { \
+            if (sp > 0) { \
+                if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; CRT_FINISH(); } \
+                else { if (COUNT) lc.pops++; --sp; ref = stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK]; } \
+            } else CRT_FINISH(); } while (0)
+
+        for (;;) {
+            if (ITERS) { if (first_active_lane()) lc.pops++; }
+            if (!active) {
+                if (cand == 0) break;                                  // this lane is done with the chunk
+                const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
+                cand &= cand - 1;
+                curInst = base + k;
+                const CrtDevInstance* ip = S.devInstances + curInst;
+                CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
+                mo = xform_xyz(I, o.x, o.y, o.z, 1.0f);
+                md = xform_xyz(I, d.x, d.y, d.z, 0.0f);              // not renormalised (hazard H6)
+                inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);    // native_recip pinned to IEEE
+                tr.t = c.distance; tr.tri = 0; tr.u = 0.0f; tr.v = 0.0f;
+                ref = __float_as_uint(I.r0.w);                       // the root is popped immediately: sp 1 -> 0, protection 0 -> 1
+                sp = 0; prot = 1; inters = 0; active = true;
+                if (COUNT) { lc.traversals++; lc.pops++; }
+                if (ITERS) { if (first_active_lane()) lc.traversals++; }
+            }
+            while (active && !(ref & CRT_LEAF_BIT)) {
+                const float4* p = S.pairs + (size_t)ref * 4;
+                const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+                if (COUNT) lc.innerVisits++;
+                if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
+                float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
+                float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
+                uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
+                if (dist1 > dist2) {
+                    float tf = dist1; dist1 = dist2; dist2 = tf;
+                    uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
+                }
+                if (dist1 == 1e30f) { CRT_POP_NEXT(); }
+                else {
+                    ref = nearRef;
+                    if (dist2 != 1e30f) {
+                        if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
+                        stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] = farRef;
+                        sp++;
+                        if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
+                    }
+                }
+            }
+            if (active) {   // ref is a leaf
+                if (ITERS) { if (first_active_lane()) lc.triTests++; }
+                const uint32_t first = ref & 0x00FFFFFFu;
+                uint32_t n = (ref >> 24) & 0x7Fu;
+                if (n == 0) n = S.bigLeaf[first];
+                for (uint32_t i = first, end = first + n; i < end; ++i) {
+                    if (COUNT) lc.triTests++;
+                    inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
+                }
+                CRT_POP_NEXT();
+            }
         }
+#undef CRT_POP_NEXT
+#undef CRT_FINISH
     }
     return c;
 }
@@ -299,23 +352,23 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
         ps.result = add3(ps.result, mul3(skyc, ps.energy));
         return false;
     }
-    const CrtMeshInstance* inst = S.instances + c.hitInstance;
-    const float* m = &inst->inverseTransform.m[0][0];
+    const CrtDevInstance* ip = S.devInstances + c.hitInstance;
+    CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
     // meshRay of the winning instance, recomputed with the same arithmetic as in the loop
-    const v3 mo = matmul_xyz(m, ps.o.x, ps.o.y, ps.o.z, 1.0f);
-    const v3 md = matmul_xyz(m, ps.d.x, ps.d.y, ps.d.z, 0.0f);
+    const v3 mo = xform_xyz(I, ps.o.x, ps.o.y, ps.o.z, 1.0f);
+    const v3 md = xform_xyz(I, ps.d.x, ps.d.y, ps.d.z, 0.0f);
 
     const uint4 c0 = S.triCold[(size_t)c.hit.tri * 2], c1 = S.triCold[(size_t)c.hit.tri * 2 + 1];
     // c0 = {uv0x|uv0y, uv1x|uv1y, uv2x|uv2y, mat|n0x}; c1 = {n0y|n0z, n1x|n1y, n1z|n2x, n2y|n2z}
     const uint32_t matIndex = c0.w & 0xffffu;
-    uint32_t mi = (uint32_t)inst->materialStart + matIndex;
+    uint32_t mi = __float_as_uint(I.r1.w) + matIndex;
     mi = mi < (uint32_t)CRT_MAX_MATERIALS ? mi : (uint32_t)CRT_MAX_MATERIALS - 1;
     const CrtMaterial mat = S.materials[mi];
     const float bx = (1.0f - c.hit.u) - c.hit.v, by = c.hit.u, bz = c.hit.v;
 
-    const v3 n0 = mat3mul(m, mk3(h2f(c0.w >> 16), h2f(c1.x & 0xffffu), h2f(c1.x >> 16)));
-    const v3 n1 = mat3mul(m, mk3(h2f(c1.y & 0xffffu), h2f(c1.y >> 16), h2f(c1.z & 0xffffu)));
-    const v3 n2 = mat3mul(m, mk3(h2f(c1.z >> 16), h2f(c1.w & 0xffffu), h2f(c1.w >> 16)));
+    const v3 n0 = mat3mul(I, mk3(h2f(c0.w >> 16), h2f(c1.x & 0xffffu), h2f(c1.x >> 16)));
+    const v3 n1 = mat3mul(I, mk3(h2f(c1.y & 0xffffu), h2f(c1.y >> 16), h2f(c1.z & 0xffffu)));
+    const v3 n2 = mat3mul(I, mk3(h2f(c1.z >> 16), h2f(c1.w & 0xffffu), h2f(c1.w >> 16)));
     const v3 normal = normalize3(add3(add3(scale3(n0, bx), scale3(n1, by)), scale3(n2, bz)));
 
     const float uvx = (h2f(c0.x & 0xffffu) * bx + h2f(c0.y & 0xffffu) * by) + h2f(c0.z & 0xffffu) * bz;

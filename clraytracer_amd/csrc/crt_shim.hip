@@ -45,13 +45,12 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
     lc.traversals = lc.pops = lc.innerVisits = lc.triTests = lc.capHits = lc.stackOverflows = lc.maxStack = 0;
 }
 
-// Pixel of this lane. A 256-thread workgroup owns a 16x16 tile; each wave64 an 8x8 sub-tile in
-// Morton order (coherent ray packets). Workgroups are dealt round-robin over the 8 XCDs (block b
-// runs on XCD b % 8), so block b takes tile row (b/8 / tilesX) * 8 + b % 8: every XCD (own 4 MiB
-// L2) walks whole tile rows left to right -- neighbouring tiles share BVH subtrees in its L2 --
-// while the eight XCDs interleave row by row, which keeps them equally loaded when geometry is
-// concentrated in one part of the frame (a contiguous slab per XCD left most XCDs idle: measured
-// ~1.2 resident waves/SIMD instead of 5).
+// Pixel of this lane. One wave64 per workgroup owns an 8x8 pixel tile, lanes in Morton order
+// (coherent ray packets). Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
+// b % 8), so block b takes tile row (b/8 / tilesX) * 8 + b % 8: every XCD (own 4 MiB L2) walks whole
+// tile rows left to right -- neighbouring tiles share BVH subtrees in its L2 -- while the eight XCDs
+// interleave row by row, which keeps them equally loaded when geometry is concentrated in one part
+// of the frame (a contiguous slab per XCD left most XCDs idle: ~1.2 resident waves/SIMD measured).
 __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py)
 {
     const int b = blockIdx.x;
@@ -62,11 +61,11 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py)
     if (k >= F.ownedTileRows) return false;
     const int bandK = k / F.tileRowsPerBand;
     const int tileRow = (F.rank + bandK * F.nRanks) * F.tileRowsPerBand + (k - bandK * F.tileRowsPerBand);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
     const int ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
-    px = tx * CRT_TILE + (wave & 1) * 8 + lx;
-    py = tileRow * CRT_TILE + (wave >> 1) * 8 + ly;
+    px = tx * CRT_TILE + lx;
+    py = tileRow * CRT_TILE + ly;
     return px < F.width && py < F.height;
 }
 
@@ -76,7 +75,7 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py)
 // STAMP (diagnostic build only, CRT_RENDER_STAMPS): every wave records start/end s_memrealtime (100 MHz),
 // its s_memtime cycle count and XCC/HW ids into a buffer nothing else reads.
 template <bool COUNT, bool STAMP = false>
-__global__ __launch_bounds__(CRT_BLOCK) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                               unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_trace_kernel(CrtDevScene S, Crt
         ps.atm = scale3(mk3(0.255f, 0.25f, 0.27f), 1.0f);
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
+            Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, lc);
             bool cont = shade_bounce(S, c, ps);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
             if (!cont) break;
@@ -106,8 +105,11 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_trace_kernel(CrtDevScene S, Crt
     if (COUNT) flush_counters(lc, counters);
     if (STAMP) {
         const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1rt = __builtin_amdgcn_s_memrealtime();
+        const uint32_t wOuter = wave_sum(lc.pops), wEnter = wave_sum(lc.traversals), wDescent = wave_sum(lc.innerVisits),
+                       wLeaf = wave_sum(lc.triTests), laneVisits = wave_sum(lc.rays);
         if ((threadIdx.x & 63) == 0) {
-            unsigned long long* st = counters + 16 + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+            unsigned long long* st = counters + 16 + (size_t)blockIdx.x * 8;
+            st[4] = wOuter; st[5] = wEnter; st[6] = wDescent; st[7] = ((unsigned long long)wLeaf << 32) | laneVisits;
             st[0] = t0rt; st[1] = t1rt; st[2] = t1c - t0c;
             st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
         }
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_postprocess_kernel(CrtFrame F, 
 }
 
 // closest-hit query over explicit rays (hit-record parity)
-__global__ __launch_bounds__(CRT_BLOCK) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
@@ -237,6 +239,21 @@ __global__ void crt_make_root_refs(const CrtBVHNode* __restrict__ raw, uint32_t 
     rootRefs[k] = make_ref(raw[r], r, nodeCount, triCap, bigLeaf, err);
 }
 
+__global__ void crt_relayout_instances(const CrtMeshInstance* __restrict__ raw, const uint32_t* __restrict__ rootRefs,
+                                       uint32_t count, CrtDevInstance* __restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const CrtMeshInstance m = raw[i];
+    const uint32_t mesh = m.meshIndex < CRT_MAX_MESHES ? m.meshIndex : 0;
+    CrtDevInstance d;
+    d.r0 = make_float4(m.inverseTransform.m[0][0], m.inverseTransform.m[0][1], m.inverseTransform.m[0][2], __uint_as_float(rootRefs[mesh]));
+    d.r1 = make_float4(m.inverseTransform.m[1][0], m.inverseTransform.m[1][1], m.inverseTransform.m[1][2], __uint_as_float((uint32_t)m.materialStart));
+    d.r2 = make_float4(m.inverseTransform.m[2][0], m.inverseTransform.m[2][1], m.inverseTransform.m[2][2], 0.0f);
+    d.r3 = make_float4(m.inverseTransform.m[3][0], m.inverseTransform.m[3][1], m.inverseTransform.m[3][2], 0.0f);
+    out[i] = d;
+}
+
 __global__ void crt_relayout_texels(const uint8_t* __restrict__ raw, size_t firstTexel, size_t count, uint32_t* __restrict__ texels)
 {
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,7 +282,7 @@ struct State {
     float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
     uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr;
     CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
-    float4* instBounds = nullptr;
+    float4* instBounds = nullptr; CrtDevInstance* devInstances = nullptr;
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
     float* rays = nullptr; float4* out = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
@@ -313,7 +330,7 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
 void fill_scene(CrtDevScene& S, uint32_t numInstances)
 {
     S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs;
-    S.instances = g.instances; S.instBounds = g.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
+    S.instances = g.instances; S.devInstances = g.devInstances; S.instBounds = g.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
     S.numTexels = (int)((g.texelBytesHigh + 2) / 3);
     if (S.numTexels < 1) S.numTexels = 1;
     S.numInstances = numInstances;
@@ -411,6 +428,8 @@ int rebuild_instance_bounds()
         bounds[i] = b;
     }
     HIPCHK(hipMemcpyAsync(g.instBounds, bounds, sizeof bounds, hipMemcpyHostToDevice, g.stream));
+    crt_relayout_instances<<<(CRT_MAX_INSTANCES + 255) / 256, 256, 0, g.stream>>>(g.instances, g.rootRefs, CRT_MAX_INSTANCES, g.devInstances);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
     return CRT_OK;
 }
@@ -487,6 +506,7 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
     HIPCHK(hipMalloc(&g.instBounds, CRT_MAX_INSTANCES * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.devInstances, CRT_MAX_INSTANCES * sizeof(CrtDevInstance)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMalloc(&g.counters, 12 * sizeof(unsigned long long)));
@@ -514,7 +534,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -533,14 +553,14 @@ int crt_resize(int width, int height)
 int crt_set_row_bands(int bandRows, int rank, int nRanks)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    if (bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
+    if (bandRows < 16 || bandRows % 16 != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
     g.bandRows = bandRows; g.rank = rank; g.nRanks = nRanks;
     return CRT_OK;
 }
 
 int crt_row_owner(int row, int bandRows, int nRanks)
 {
-    if (row < 0 || bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1) return CRT_E_BAD_ARGUMENT;
+    if (row < 0 || bandRows < 16 || bandRows % 16 != 0 || nRanks < 1) return CRT_E_BAD_ARGUMENT;
     return (row / bandRows) % nRanks;
 }
 
@@ -668,14 +688,14 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     }
     HIPCHK(hipEventRecord(g.ev[1], g.stream));
     if (flags & CRT_RENDER_STAMPS) {
-        const size_t need = (16 + (size_t)grid * 16) * sizeof(unsigned long long);
+        const size_t need = (16 + (size_t)grid * 8) * sizeof(unsigned long long);
         if (need > g.stampBytes) {
             if (g.stamps) (void)hipFree(g.stamps);
             g.stamps = nullptr; g.stampBytes = 0;
             HIPCHK(hipMalloc(&g.stamps, need));
             g.stampBytes = need;
         }
-        g.stampWaves = (size_t)grid * 4;
+        g.stampWaves = (size_t)grid;
         HIPCHK(hipMemsetAsync(g.stamps, 0, need, g.stream));
         crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
     } else if (flags & CRT_RENDER_COUNTERS) {
@@ -782,7 +802,7 @@ int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
     if (!dst || !g.stamps) return CRT_OK;
     const size_t n = maxWaves < g.stampWaves ? maxWaves : g.stampWaves;
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(dst, g.stamps + 16, n * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, g.stamps + 16, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

@@ -103,8 +103,9 @@ int crt_owned_rows(void);                                     /* rows this rank 
  * which: 0 = whole frame, 1 = RayGen (only with WRITE_RAYS), 2 = Trace, 3 = PostProcess. */
 float crt_last_kernel_ms(int which);
 int crt_get_counters(CrtCounters* out);
-/* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 4 x uint64 {start, end (s_memrealtime, 100 MHz),
- * shader cycles, XCC_ID | HW_ID << 32}. Pass dst = NULL to query the wave count. */
+/* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 8 x uint64 {start, end (s_memrealtime, 100 MHz),
+ * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer / enter-instance / descent loops,
+ * leaf trips << 32 | lane-level node visits}. Pass dst = NULL to query the wave count. */
 int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves);
 
 const char* crt_error_string(int code);

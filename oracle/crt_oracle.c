@@ -159,6 +159,10 @@ float orc_intersect_aabb(const float o[3], const float invDir[3], const float bm
 /* ------------------------------------------------------------------------------------------
  * kernel_main.cl:124-160  IntersectBVH
  * ---------------------------------------------------------------------------------------- */
+/* Analysis hook: when set, every child-pair fetch increments visitCounts[leftIndex]. */
+static uint32_t* g_visit_counts = NULL;
+void orc_set_visit_counts(uint32_t* counts) { g_visit_counts = counts; }
+
 static int intersect_bvh(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode, const CrtTri* tris,
                          Triout* out, OrcStats* st)
 {
@@ -188,6 +192,10 @@ static int intersect_bvh(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode, co
             const CrtBVHNode* l = nodes + leftIndex;
             const CrtBVHNode* r = nodes + rightIndex;
             st->innerVisits++;
+            if (g_visit_counts) {
+#pragma omp atomic
+                g_visit_counts[leftIndex]++;
+            }
             float dist1 = intersect_aabb(ray.origin, invDir, f3_make(l->aabbMin[0], l->aabbMin[1], l->aabbMin[2]),
                                          f3_make(l->aabbMax[0], l->aabbMax[1], l->aabbMax[2]), out->t);
             float dist2 = intersect_aabb(ray.origin, invDir, f3_make(r->aabbMin[0], r->aabbMin[1], r->aabbMin[2]),
@@ -439,6 +447,27 @@ void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, i
         stats_add(&total, &st);
     }
     if (stats) stats_add(stats, &total);
+}
+
+/* Analysis helper: per-pixel work (inner visits + triangle tests over both bounces) of a frame. */
+void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
+                     uint32_t* innerOut, uint32_t* triOut, int nthreads)
+{
+    const float lightY = (float)sin((double)args->sunAngle);
+    const float lightZ = (float)cos((double)args->sunAngle);
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+    for (int j = 0; j < height; ++j) {
+        for (int i = 0; i < width; ++i) {
+            size_t idx = (size_t)j * (size_t)width + (size_t)i;
+            OrcStats st; memset(&st, 0, sizeof st);
+            float px[4];
+            f3 d = f3_make(rays[3 * idx], rays[3 * idx + 1], rays[3 * idx + 2]);
+            trace_pixel(s, args, d, lightY, lightZ, px, &st);
+            innerOut[idx] = (uint32_t)st.innerVisits;
+            triOut[idx] = (uint32_t)st.triTests;
+        }
+    }
 }
 
 void orc_closest_hits(const OrcScene* s, const float* origins, const float* dirs, int n,

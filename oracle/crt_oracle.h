@@ -105,6 +105,11 @@ void orc_raygen(float* rays, int width, int height, const float invView[16], con
 void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                int row0, int row1, float* out, OrcStats* stats, int nthreads);
 void orc_postprocess(float* rgba, int width, int height, int row0, int row1);
+/* Analysis helper: per-pixel inner visits / triangle tests (both bounces) of a full frame. */
+void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
+                     uint32_t* innerOut, uint32_t* triOut, int nthreads);
+/* Analysis hook: count child-pair fetches per left-child index (NULL disables). */
+void orc_set_visit_counts(uint32_t* counts);
 /* Closest-hit query for arbitrary world-space rays: the instance loop of kernel_main.cl:198-217. */
 void orc_closest_hits(const OrcScene* s, const float* origins, const float* dirs, int n,
                       CrtRayHit* out, OrcStats* stats, int nthreads);

@@ -21,7 +21,7 @@ with driver.Session(w, h, device=0) as s:
     s.render_raw(16)
     n = C.c_size_t(0)
     _lib.check(s.hip.crt_debug_read_stamps(None, 0, C.byref(n)))
-    st = np.zeros((n.value, 4), np.uint64)
+    st = np.zeros((n.value, 8), np.uint64)
     _lib.check(s.hip.crt_debug_read_stamps(st.ctypes.data, n.value, C.byref(n)))
     ms = s.kernel_ms(2)
 st = st[st[:, 1] > 0]
@@ -42,5 +42,12 @@ for x in range(8):
     m = xcc == x
     if m.any():
         print(f"XCC {x}: {m.sum()} waves, first start {start[m].min():.1f}, last end {end[m].max():.1f}, sum dur {dur[m].sum() / 1e3:.1f} ms")
+outer, enter, desc = st[:, 4].astype(np.float64), st[:, 5].astype(np.float64), st[:, 6].astype(np.float64)
+leaf, lanev = (st[:, 7] >> np.uint64(32)).astype(np.float64), (st[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
+cyc = st[:, 2].astype(np.float64)
+print("wave-level loop trips (sum over waves): outer %.2fM enter %.2fM descent %.2fM leaf %.2fM ; lane-level node visits %.2fM -> lanes active per descent trip %.1f" % (
+    outer.sum() / 1e6, enter.sum() / 1e6, desc.sum() / 1e6, leaf.sum() / 1e6, lanev.sum() / 1e6, lanev.sum() / max(1.0, desc.sum())))
+print("cycles per descent trip: all waves %.0f ; slowest 1%% of waves %.0f" % (cyc.sum() / max(1.0, desc.sum()), cyc[dur >= np.percentile(dur, 99)].sum() / max(1.0, desc[dur >= np.percentile(dur, 99)].sum())))
 top = np.argsort(-dur)[:8]
+print("slowest waves: descent trips", desc[top].astype(int), "leaf trips", leaf[top].astype(int), "enter", enter[top].astype(int), "lane visits", lanev[top].astype(int))
 print("slowest waves (us):", np.round(dur[top], 1), "start", np.round(start[top], 1))
