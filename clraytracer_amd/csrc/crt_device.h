@@ -33,7 +33,19 @@
 
 #define CRT_LEAF_BIT 0x80000000u
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
-#define CRT_WAVES_PER_SIMD 5   // 20 waves per CU is what the 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
+#ifndef CRT_WAVES_PER_SIMD
+#define CRT_WAVES_PER_SIMD 5
+#endif
+//  // 20 waves per CU is what the 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
+// Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126). Slots 0..CRT_LDS_SLOTS-1 of every
+// lane live in LDS (slot s of lane l at stack[s * 64 + l]: conflict-free), the rarely reached deeper slots in a
+// private (scratch) array, so a wave needs CRT_LDS_SLOTS * 256 B of LDS instead of 8 KiB and more waves fit a CU.
+#ifndef CRT_LDS_SLOTS
+#define CRT_LDS_SLOTS 16
+#endif
+#define CRT_STACK_DECL(name) __shared__ uint32_t name##_lds[CRT_LDS_SLOTS * CRT_BLOCK]; uint32_t spill[CRT_STACK_DEPTH - CRT_LDS_SLOTS]; uint32_t* stack = name##_lds + threadIdx.x
+#define CRT_STACK_WRITE(slot, v) do { const int s_ = (slot) & (CRT_STACK_DEPTH - 1); if (s_ < CRT_LDS_SLOTS) stack[s_ * CRT_BLOCK] = (v); else spill[s_ - CRT_LDS_SLOTS] = (v); } while (0)
+#define CRT_STACK_READ(slot) ((((slot) & (CRT_STACK_DEPTH - 1)) < CRT_LDS_SLOTS) ? stack[((slot) & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] : spill[((slot) & (CRT_STACK_DEPTH - 1)) - CRT_LDS_SLOTS])
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 
 struct CrtDevScene {
@@ -207,7 +219,7 @@ __device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
 // The traversal stack lives in LDS (32 slots x 64 lanes x 4 B = 8 KiB per wave; slot s of this lane at
 // stack[s * 64], conflict-free); slot indices wrap modulo 32 where upstream would overflow its array.
 template <bool COUNT, bool ITERS = false>
-__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, uint32_t* stack, LaneCounters& lc)
+__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, uint32_t* stack, uint32_t* spill, LaneCounters& lc)
 {
     Closest c;
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
@@ -239,60 +251,76 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
 #define CRT_POP_NEXT() do { \
             if (sp > 0) { \
                 if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; CRT_FINISH(); } \
-                else { if (COUNT) lc.pops++; --sp; ref = stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK]; } \
+                else { if (COUNT) lc.pops++; --sp; ref = CRT_STACK_READ(sp); } \
             } else CRT_FINISH(); } while (0)
 
+        // Flat trips with a vote: exactly one step kind (inner node / leaf / enter next instance) runs per
+        // trip, the one most lanes are waiting for. No lane waits for a neighbour's whole descent, so the
+        // number of trips a wave needs approaches its slowest lane's own step count (measured on multi-1M:
+        // the nested descend-then-leaf loops needed 1979 trips for a tile whose longest ray has 361 visits).
+        bool done = false;
         for (;;) {
+            const bool wEnter = !done && !active;
+            const bool wInner = !done && active && !(ref & CRT_LEAF_BIT);
+            const bool wLeaf = !done && active && (ref & CRT_LEAF_BIT);
+            const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
+            if (nE + nI + nL == 0) break;
             if (ITERS) { if (first_active_lane()) lc.pops++; }
-            if (!active) {
-                if (cand == 0) break;                                  // this lane is done with the chunk
-                const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
-                cand &= cand - 1;
-                curInst = base + k;
-                const CrtDevInstance* ip = S.devInstances + curInst;
-                CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
-                mo = xform_xyz(I, o.x, o.y, o.z, 1.0f);
-                md = xform_xyz(I, d.x, d.y, d.z, 0.0f);              // not renormalised (hazard H6)
-                inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);    // native_recip pinned to IEEE
-                tr.t = c.distance; tr.tri = 0; tr.u = 0.0f; tr.v = 0.0f;
-                ref = __float_as_uint(I.r0.w);                       // the root is popped immediately: sp 1 -> 0, protection 0 -> 1
-                sp = 0; prot = 1; inters = 0; active = true;
-                if (COUNT) { lc.traversals++; lc.pops++; }
-                if (ITERS) { if (first_active_lane()) lc.traversals++; }
-            }
-            while (active && !(ref & CRT_LEAF_BIT)) {
-                const float4* p = S.pairs + (size_t)ref * 4;
-                const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
-                if (COUNT) lc.innerVisits++;
-                if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
-                float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
-                float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
-                uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
-                if (dist1 > dist2) {
-                    float tf = dist1; dist1 = dist2; dist2 = tf;
-                    uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
-                }
-                if (dist1 == 1e30f) { CRT_POP_NEXT(); }
-                else {
-                    ref = nearRef;
-                    if (dist2 != 1e30f) {
-                        if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
-                        stack[(sp & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] = farRef;
-                        sp++;
-                        if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
+            if (nI > 0 && nI >= nE && nI >= nL) {
+                if (wInner) {
+                    const float4* p = S.pairs + (size_t)ref * 4;
+                    const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+                    if (COUNT) lc.innerVisits++;
+                    if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
+                    float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
+                    float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
+                    uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
+                    if (dist1 > dist2) {
+                        float tf = dist1; dist1 = dist2; dist2 = tf;
+                        uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
+                    }
+                    if (dist1 == 1e30f) { CRT_POP_NEXT(); }
+                    else {
+                        ref = nearRef;
+                        if (dist2 != 1e30f) {
+                            if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
+                            CRT_STACK_WRITE(sp, farRef);
+                            sp++;
+                            if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
+                        }
                     }
                 }
-            }
-            if (active) {   // ref is a leaf
-                if (ITERS) { if (first_active_lane()) lc.triTests++; }
-                const uint32_t first = ref & 0x00FFFFFFu;
-                uint32_t n = (ref >> 24) & 0x7Fu;
-                if (n == 0) n = S.bigLeaf[first];
-                for (uint32_t i = first, end = first + n; i < end; ++i) {
-                    if (COUNT) lc.triTests++;
-                    inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
+            } else if (nL > 0 && nL >= nE) {
+                if (wLeaf) {
+                    if (ITERS) { if (first_active_lane()) lc.triTests++; }
+                    const uint32_t first = ref & 0x00FFFFFFu;
+                    uint32_t n = (ref >> 24) & 0x7Fu;
+                    if (n == 0) n = S.bigLeaf[first];
+                    for (uint32_t i = first, end = first + n; i < end; ++i) {
+                        if (COUNT) lc.triTests++;
+                        inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
+                    }
+                    CRT_POP_NEXT();
                 }
-                CRT_POP_NEXT();
+            } else {
+                if (wEnter) {
+                    if (cand == 0) done = true;                            // this lane is finished with the chunk
+                    else {
+                        if (ITERS) { if (first_active_lane()) lc.traversals++; }
+                        const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
+                        cand &= cand - 1;
+                        curInst = base + k;
+                        const CrtDevInstance* ip = S.devInstances + curInst;
+                        CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
+                        mo = xform_xyz(I, o.x, o.y, o.z, 1.0f);
+                        md = xform_xyz(I, d.x, d.y, d.z, 0.0f);              // not renormalised (hazard H6)
+                        inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);    // native_recip pinned to IEEE
+                        tr.t = c.distance; tr.tri = 0; tr.u = 0.0f; tr.v = 0.0f;
+                        ref = __float_as_uint(I.r0.w);                       // the root is popped immediately: sp 1 -> 0, protection 0 -> 1
+                        sp = 0; prot = 1; inters = 0; active = true;
+                        if (COUNT) { lc.traversals++; lc.pops++; }
+                    }
+                }
             }
         }
 #undef CRT_POP_NEXT
@@ -304,7 +332,9 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
 __device__ __forceinline__ int clamp_texel(int idx, int n) { return idx < 0 ? 0 : (idx >= n ? n - 1 : idx); }
 
 // MathAndSTL.cl:253-258 (hard-wired to textures[2] and pool offset 2 upstream, hazard H9)
-__device__ __forceinline__ int sample_skybox(v3 d, int texW, int texH)
+// Out of line on purpose: the double-precision atan2/acos expansion needs ~60 VGPRs of temporaries; inlined
+// into the persistent kernel it forced the per-lane traversal state into scratch inside the hot loop.
+__device__ __noinline__ int sample_skybox(v3 d, int texW, int texH)
 {
     const double PI = 3.14159265358979323846;
     float at = (float)(atan2((double)d.x, (double)(-d.z)) / PI);
@@ -339,9 +369,13 @@ __device__ __forceinline__ v3 raygen_dir(const CrtFrame& F, int i, int j)
 
 // One bounce of kernel_main.cl:187-272 after the closest hit is known. Returns false when the
 // path terminated (miss -> skybox). On a hit, updates ray/energy/atmospheric/lightDir in place.
-struct PathState { v3 o, d, result, energy, atm, light; };
+// Per-path state carried across the two bounces (kernel_main.cl:179-187). Upstream also carries
+//   energy (float3): starts (1,1,1) and is only ever multiplied by a splat (kernel_main.cl:264,268) -> one float;
+//   atmosphericLight: (0.255,0.25,0.27)*1 at bounce 0, that * 0.4 at bounce 1 (kernel_main.cl:185,269) -> from `bounce`;
+//   lightDir: the sun at bounce 0, the bounce ray's direction at bounce 1 (kernel_main.cl:181,271) -> from `bounce`.
+struct PathState { v3 o, d, result; float energy; };
 
-__device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest& c, PathState& ps)
+__device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest& c, PathState& ps, int bounce, float lightY, float lightZ)
 {
     const float UcharToFloat01 = 1.0f / 255.0f;
     if (c.distance > 99998.0f) {
@@ -349,9 +383,12 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
         int idx = clamp_texel(sample_skybox(ps.d, sky.width, sky.height), S.numTexels);
         uint32_t px = S.texels[idx];
         v3 skyc = scale3(mk3((float)(px & 0xffu), (float)((px >> 8) & 0xffu), (float)((px >> 16) & 0xffu)), UcharToFloat01);
-        ps.result = add3(ps.result, mul3(skyc, ps.energy));
+        ps.result = add3(ps.result, scale3(skyc, ps.energy));
         return false;
     }
+    const v3 light = bounce == 0 ? mk3(0.0f, lightY, lightZ) : ps.d;     // lightDir = ray.direction after the first bounce
+    const v3 atm0 = scale3(mk3(0.255f, 0.25f, 0.27f), 1.0f);
+    const v3 atm = bounce == 0 ? atm0 : scale3(atm0, 0.4f);
     const CrtDevInstance* ip = S.devInstances + c.hitInstance;
     CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
     // meshRay of the winning instance, recomputed with the same arithmetic as in the loop
@@ -393,17 +430,15 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
     ps.o = add3(point, scale3(normal, 0.01f));
     ps.d = reflect3(ps.d, normal);
 
-    float ndl = dot3(normal, neg3(ps.light));
-    const v3 ambient = mul3(scale3(ps.atm, fmaxf(0.0f - ndl, 0.1f)), color);
+    float ndl = dot3(normal, neg3(light));
+    const v3 ambient = mul3(scale3(atm, fmaxf(0.0f - ndl, 0.1f)), color);
     ndl = fmaxf(ndl, 0.0f);
     const float sp = ((1.0f - roughness) * ndl) * shadow;
     const v3 specular = scale3(mul3(mk3(sp, sp, sp), specularColor), ndl);
     // pow(x, shininess) with shininess == 1.0f (kernel_main.cl:250) is exactly x
-    const float sl = (ndl * fmaxf(dot3(reflect3(neg3(ps.light), normal), md), 0.0f)) * 0.2f;
+    const float sl = (ndl * fmaxf(dot3(reflect3(neg3(light), normal), md), 0.0f)) * 0.2f;
 
-    ps.result = add3(ps.result, add3(add3(mul3(ps.energy, scale3(color, ndl)), ambient), mk3(sl, sl, sl)));
-    ps.energy = mul3(ps.energy, specular);
-    ps.atm = scale3(ps.atm, 0.4f);
-    ps.light = ps.d;
+    ps.result = add3(ps.result, add3(add3(scale3(scale3(color, ndl), ps.energy), ambient), mk3(sl, sl, sl)));
+    ps.energy = ps.energy * specular.x;
     return true;
 }

@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/crt_api.h"
 #include "crt_device.h"
 
@@ -45,6 +46,8 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
     lc.traversals = lc.pops = lc.innerVisits = lc.triTests = lc.capHits = lc.stackOverflows = lc.maxStack = 0;
 }
 
+#include "crt_persistent.h"
+
 // Pixel of this lane. One wave64 per workgroup owns an 8x8 pixel tile, lanes in Morton order
 // (coherent ray packets). Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
 // b % 8), so block b takes tile row (b/8 / tilesX) * 8 + b % 8: every XCD (own 4 MiB L2) walks whole
@@ -78,8 +81,7 @@ template <bool COUNT, bool STAMP = false>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                               unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
-    uint32_t* stack = s_stack + threadIdx.x;
+    CRT_STACK_DECL(s_stack);
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
     if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
@@ -89,14 +91,12 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
         PathState ps;
         ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
         ps.d = raygen_dir(F, px, py);
-        ps.light = mk3(0.0f, F.lightY, F.lightZ);
         ps.result = mk3(0.0f, 0.0f, 0.0f);
-        ps.energy = mk3(1.0f, 1.0f, 1.0f);
-        ps.atm = scale3(mk3(0.255f, 0.25f, 0.27f), 1.0f);
+        ps.energy = 1.0f;
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, lc);
-            bool cont = shade_bounce(S, c, ps);
+            Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, spill, lc);
+            bool cont = shade_bounce(S, c, ps, bounce, F.lightY, F.lightZ);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
             if (!cont) break;
         }
@@ -161,15 +161,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
-    uint32_t* stack = s_stack + threadIdx.x;
+    CRT_STACK_DECL(s_stack);
     LaneCounters lc; zero_counters(lc);
     const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;
     if (k < n) {
         v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
         v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
         lc.rays++;
-        Closest c = closest_hit<true>(S, o, d, stack, lc);
+        Closest c = closest_hit<true>(S, o, d, stack, spill, lc);
         CrtRayHit h;
         if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
         else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }
@@ -287,6 +286,7 @@ struct State {
     float* rays = nullptr; float4* out = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
+    CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
     uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
@@ -511,6 +511,10 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMalloc(&g.counters, 12 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
+    HIPCHK(hipMalloc(&g.queues, sizeof(CrtQueues)));
+    g.numCUs = prop.multiProcessorCount;
+    { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); }  // default: tile kernel (faster)
+    { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.rootRefs, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.instances, 0, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
@@ -534,7 +538,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -695,9 +699,30 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
             HIPCHK(hipMalloc(&g.stamps, need));
             g.stampBytes = need;
         }
-        g.stampWaves = (size_t)grid;
         HIPCHK(hipMemsetAsync(g.stamps, 0, need, g.stream));
-        crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
+        if (g.persistent) {
+            const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
+            unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);
+            if (waves > tiles) waves = tiles;
+            g.stampWaves = waves;
+            HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
+            crt_trace_persistent_kernel<false, true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps, g.queues);
+        } else {
+            g.stampWaves = (size_t)grid;
+            crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
+        }
+    } else if (g.persistent) {
+        // persistent waves pulling tiles from per-XCD queues (crt_persistent.h)
+        const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
+        unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);
+        if (waves > tiles) waves = tiles;
+        HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
+        if (flags & CRT_RENDER_COUNTERS) {
+            HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
+            crt_trace_persistent_kernel<true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
+        } else {
+            crt_trace_persistent_kernel<false><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
+        }
     } else if (flags & CRT_RENDER_COUNTERS) {
         HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
         crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);

@@ -42,6 +42,14 @@ for x in range(8):
     m = xcc == x
     if m.any():
         print(f"XCC {x}: {m.sum()} waves, first start {start[m].min():.1f}, last end {end[m].max():.1f}, sum dur {dur[m].sum() / 1e3:.1f} ms")
+if os.environ.get("CRT_KERNEL", "tile") == "persistent":
+    hi = lambda a: (a >> np.uint64(32)).astype(np.float64).sum()
+    lo = lambda a: (a & np.uint64(0xFFFFFFFF)).astype(np.float64).sum()
+    cyc = st[:, 2].astype(np.float64)
+    for nm, col in (("service", 4), ("inner", 5), ("leaf", 6), ("enter", 7)):
+        print("%-8s passes/trips %.3fM  lanes %.2fM  -> %.1f lanes per trip" % (nm, hi(st[:, col]) / 1e6, lo(st[:, col]) / 1e6, lo(st[:, col]) / max(1.0, hi(st[:, col]))))
+    print("cycles per wave: mean %.0f max %.0f ; total wave-cycles %.2fG" % (cyc.mean(), cyc.max(), cyc.sum() / 1e9))
+    sys.exit(0)
 outer, enter, desc = st[:, 4].astype(np.float64), st[:, 5].astype(np.float64), st[:, 6].astype(np.float64)
 leaf, lanev = (st[:, 7] >> np.uint64(32)).astype(np.float64), (st[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
 cyc = st[:, 2].astype(np.float64)
