@@ -44,6 +44,23 @@ def algorithmic_bytes(c, pixels):
     return per_ray + per_hit + per_miss + per_pixel
 
 
+COUNTER_KEYS = ["rays", "primary", "secondary", "hits", "misses", "traversals", "pops", "innerVisits", "triTests"]
+
+
+def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device):
+    """Whole-job totals: SUM of the per-rank work counters / pixels / algorithmic bytes, MAX of the per-rank times.
+    `dist` is torch.distributed (initialised) or None for a single process. No pixel data is exchanged."""
+    import torch
+    vec = torch.tensor([float(cnt[k]) for k in COUNTER_KEYS] + [float(own_pixels), float(algorithmic_bytes(cnt, own_pixels))],
+                       dtype=torch.float64, device=device)
+    tmax = torch.tensor([float(elapsed_s), float(kernel_ms_mean)], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tot = dict(zip(COUNTER_KEYS + ["pixels", "alg_bytes"], vec.tolist()))
+    return tot, tmax[0].item(), tmax[1].item()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,15 +134,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    keys = ["rays", "primary", "secondary", "hits", "misses", "traversals", "pops", "innerVisits", "triTests"]
-    vec = torch.tensor([float(cnt[k]) for k in keys] + [float(own_rows * width), float(algorithmic_bytes(cnt, own_rows * width))],
-                       dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed, float(np.mean(trace_ms))], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tot = dict(zip(keys + ["pixels", "alg_bytes"], vec.tolist()))
-    elapsed_max, kernel_ms_max = tmax.tolist()
+    tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, float(np.mean(trace_ms)), "cuda")
 
     if rank == 0:
         rays_per_frame = tot["rays"]

@@ -116,6 +116,78 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
     }
 }
 
+// ---- wavefront form of Trace: one launch per bounce with ballot compaction in between ----------------
+// The megakernel above runs bounce 1 inside the same wave as bounce 0, at the lane density of the pixels
+// that hit something (31 % on multi-1M) and on top of the wave's bounce-0 latency. Here bounce 0 writes the
+// pixel's partial result and appends {origin, direction, energy, pixel} of every continuing path to a queue:
+// the lanes of a wave that continue are found with one ballot, the wave reserves a contiguous queue range with
+// ONE atomic, and every lane stores its 32-byte record at base + (rank among the continuing lanes). Bounce 1
+// is then traced by dense 64-ray packets. Per-path arithmetic is unchanged: result = (partial) + (bounce-1
+// terms) in the same order as kernel_main.cl:267, so pixels are bit-identical to the megakernel.
+struct CrtBounceRay { float ox, oy, oz, energy, dx, dy, dz; uint32_t pixel; };   // 32 B
+
+template <bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+                                                                unsigned long long* __restrict__ counters,
+                                                                CrtBounceRay* __restrict__ queue, uint32_t* __restrict__ queueCount)
+{
+    CRT_STACK_DECL(s_stack);
+    LaneCounters lc; zero_counters(lc);
+    int px, py;
+    const bool active = lane_pixel(F, px, py);
+    bool cont = false;
+    PathState ps;
+    ps.o = mk3(0.f, 0.f, 0.f); ps.d = ps.o; ps.result = ps.o; ps.energy = 1.0f;
+    if (active) {
+        ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
+        ps.d = raygen_dir(F, px, py);
+        if (COUNT) { lc.rays++; lc.primary++; }
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, spill, lc);
+        cont = shade_bounce(S, c, ps, 0, F.lightY, F.lightZ);
+        if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
+        out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    // wave-level compaction of the continuing paths
+    const unsigned long long m = __ballot(cont);
+    if (m != 0) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(queueCount, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1, 64);
+        if (cont) {
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+            CrtBounceRay r;
+            r.ox = ps.o.x; r.oy = ps.o.y; r.oz = ps.o.z; r.energy = ps.energy;
+            r.dx = ps.d.x; r.dy = ps.d.y; r.dz = ps.d.z; r.pixel = (uint32_t)py * (uint32_t)F.width + (uint32_t)px;
+            queue[base + rank] = r;
+        }
+    }
+    if (COUNT) flush_counters(lc, counters);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+                                                               unsigned long long* __restrict__ counters,
+                                                               const CrtBounceRay* __restrict__ queue, const uint32_t* __restrict__ queueCount)
+{
+    CRT_STACK_DECL(s_stack);
+    LaneCounters lc; zero_counters(lc);
+    const uint32_t n = *queueCount;
+    const uint32_t k = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    if (k < n) {
+        const CrtBounceRay r = queue[k];
+        PathState ps;
+        ps.o = mk3(r.ox, r.oy, r.oz); ps.d = mk3(r.dx, r.dy, r.dz); ps.energy = r.energy;
+        const float4 partial = out[r.pixel];
+        ps.result = mk3(partial.x, partial.y, partial.z);
+        if (COUNT) { lc.rays++; lc.secondary++; }
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, spill, lc);
+        const bool cont = shade_bounce(S, c, ps, 1, F.lightY, F.lightZ);
+        if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
+        out[r.pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    if (COUNT) flush_counters(lc, counters);
+}
+
 // kernel RayGen as its own launch (only for CRT_RENDER_WRITE_RAYS)
 __global__ __launch_bounds__(CRT_BLOCK) void crt_raygen_kernel(CrtFrame F, float* __restrict__ rays)
 {
@@ -287,6 +359,7 @@ struct State {
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
+    int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
     uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
@@ -340,6 +413,9 @@ int alloc_frame_buffers(int w, int h)
 {
     if (g.rays) { (void)hipFree(g.rays); g.rays = nullptr; }
     if (g.out) { (void)hipFree(g.out); g.out = nullptr; }
+    if (g.bounceQueue) { (void)hipFree(g.bounceQueue); g.bounceQueue = nullptr; }
+    g.bounceCap = (size_t)w * (size_t)h;
+    HIPCHK(hipMalloc(&g.bounceQueue, sizeof(CrtBounceRay) * g.bounceCap));
     HIPCHK(hipMalloc(&g.rays, sizeof(float) * 3 * (size_t)w * (size_t)h));
     HIPCHK(hipMalloc(&g.out, sizeof(float4) * (size_t)w * (size_t)h));
     HIPCHK(hipMemsetAsync(g.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
@@ -512,8 +588,9 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.counters, 12 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
     HIPCHK(hipMalloc(&g.queues, sizeof(CrtQueues)));
+    HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
     g.numCUs = prop.multiProcessorCount;
-    { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); }  // default: tile kernel (faster)
+    { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); g.wavefront = (e && strcmp(e, "wavefront") == 0); }  // default: tile kernel (faster)
     { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.rootRefs, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
@@ -538,7 +615,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -722,6 +799,19 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
             crt_trace_persistent_kernel<true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
         } else {
             crt_trace_persistent_kernel<false><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
+        }
+    } else if (g.wavefront) {
+        // bounce 0, compaction, bounce 1 (at most one continuing path per owned pixel)
+        const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
+        const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
+        HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), g.stream));
+        if (flags & CRT_RENDER_COUNTERS) {
+            HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
+            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+        } else {
+            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
         }
     } else if (flags & CRT_RENDER_COUNTERS) {
         HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));

@@ -130,21 +130,3 @@ def test_no_instances_is_all_sky(small):
     _lib.check(s.hip.crt_render(C.byref(a), iv.ctypes.data_as(C.POINTER(C.c_float)), ip.ctypes.data_as(C.POINTER(C.c_float)), FLAG_COUNT))
     cnt = s.counters()
     assert cnt["hits"] == 0 and cnt["misses"] == s.width * s.height and cnt["traversals"] == 0
-
-
-def test_persistent_kernel_variant_is_bit_identical(nthreads, monkeypatch):
-    """The opt-in persistent-wave kernel (crt_persistent.h, CRT_KERNEL=persistent) renders the same bits."""
-    sc = scenes.get("tiny")
-    with driver.Session(256, 144, device=0) as s:
-        s.load_scene(sc)
-        s.render_raw(FLAG_COUNT)
-        ref = s.read_output(); ref_cnt = s.counters()
-    monkeypatch.setenv("CRT_KERNEL", "persistent")
-    with driver.Session(256, 144, device=0) as s:
-        s.load_scene(sc)
-        s.render_raw(FLAG_COUNT)
-        got = s.read_output(); cnt = s.counters()
-        s.render_raw(0)
-        got2 = s.read_output()
-    assert np.array_equal(bits(got), bits(ref)) and np.array_equal(bits(got2), bits(ref))
-    assert cnt == ref_cnt

@@ -1,0 +1,30 @@
+"""Opt-in kernel structures must be bit-identical to the default megakernel (own module: one device session at a time)."""
+import numpy as np
+import pytest
+
+from clraytracer_amd import driver, scenes
+from util import bits
+
+pytestmark = pytest.mark.gpu
+FLAG_COUNT = 8
+
+
+@pytest.mark.parametrize("variant", ["persistent", "wavefront"])
+def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
+    """The opt-in kernel structures (CRT_KERNEL=persistent: crt_persistent.h; CRT_KERNEL=wavefront: one launch per
+    bounce with ballot compaction) render the same bits and count the same work as the default megakernel."""
+    sc = scenes.get("tiny")
+    monkeypatch.delenv("CRT_KERNEL", raising=False)
+    with driver.Session(256, 144, device=0) as s:
+        s.load_scene(sc)
+        s.render_raw(FLAG_COUNT)
+        ref = s.read_output(); ref_cnt = s.counters()
+    monkeypatch.setenv("CRT_KERNEL", variant)
+    with driver.Session(256, 144, device=0) as s:
+        s.load_scene(sc)
+        s.render_raw(FLAG_COUNT)
+        got = s.read_output(); cnt = s.counters()
+        s.render_raw(0)
+        got2 = s.read_output()
+    assert np.array_equal(bits(got), bits(ref)) and np.array_equal(bits(got2), bits(ref))
+    assert cnt == ref_cnt
