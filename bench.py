@@ -61,6 +61,25 @@ def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device):
     return tot, tmax[0].item(), tmax[1].item()
 
 
+def pmc_traffic(kernel, workload_scene, width, height):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_summary.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command, newest round first). FETCH_SIZE is exact
+    for this kernel's 64-B record gathers (profiles/r01_fetch_calibration.md) and counts every byte leaving L2, so it
+    is an upper bound on HBM reads. Returns (bytes, source) or (None, None) when no matching profile is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            b = d.get("bench_line") or {}
+            c = d.get("counters", {})
+            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene \
+                    and b["config"].get("width") == width and b["config"].get("height") == height and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return int((c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +163,7 @@ def main():
         my_bytes = algorithmic_bytes(cnt, own_rows * width)
         my_ms = float(np.mean(trace_ms))
         achieved = my_bytes / (my_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic("crt_trace_kernel", sc.name, width, height) if n == 1 else (None, None)
         out = {
             "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -158,7 +178,7 @@ def main():
             "kernel_ms": {"crt_trace_kernel_mean": round(my_ms, 4), "crt_trace_kernel_min": round(float(np.min(trace_ms)), 4),
                           "max_over_ranks_mean": round(kernel_ms_max, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "crt_trace_kernel<false>", "algorithmic_bytes_per_launch": int(my_bytes),
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
                          "inner_visits_per_ray": round(cnt["innerVisits"] / max(1, cnt["rays"]), 2),

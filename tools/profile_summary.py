@@ -18,7 +18,10 @@ def main():
     kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false>"
     base = os.path.join(ROOT, "gpurun_out")
     out = {"tag": tag, "kernel": kern, "kernel_stats": [], "counters": {}, "bench_line": None}
-    for f in glob.glob(os.path.join(base, f"prof_{tag}_stats", "*", "*_kernel_stats.csv")):
+    def newest(pattern):
+        fs = glob.glob(pattern)
+        return [max(fs, key=os.path.getmtime)] if fs else []
+    for f in newest(os.path.join(base, f"prof_{tag}_stats", "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             out["kernel_stats"].append({"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                         "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])})
@@ -29,7 +32,7 @@ def main():
                 out["bench_line"] = json.loads(line)
     meta = {}
     for d in sorted(glob.glob(os.path.join(base, f"prof_{tag}_*"))):
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 if kern in r["Kernel_Name"]:
@@ -55,6 +58,10 @@ def main():
         d["wave_parked_fraction"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
     if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
         d["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    if "TCP_TCC_READ_REQ_sum" in c and "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+        d["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(1.0, c["TCP_TOTAL_CACHE_ACCESSES_sum"])
+    if "TCP_GATE_EN1_sum" in c and "GRBM_GUI_ACTIVE" in c:
+        d["tcp_busy_fraction_of_kernel"] = (c["TCP_GATE_EN1_sum"] / 256.0) / max(1.0, c["GRBM_GUI_ACTIVE"] / 8.0)
     out["derived"] = d
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
