@@ -1,0 +1,134 @@
+"""Edge cases of the boundary on the GPU: ragged frame sizes, the 401-instance maximum (candidate chunks of 64),
+single-leaf meshes (hazard H3), leaves with >= 128 triangles (the `bigLeaf` escape of the packed node reference),
+partial instance updates, and the error paths of the upload API."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from clraytracer_amd import _lib, driver, scenes
+import oracle_lib
+from util import bits, seeded_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def frame_equal(s, orc, sc, flags=8):
+    s.render_raw(flags)
+    gpu = s.read_output()
+    iv, ip, pos = s.camera()
+    ref, st = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
+    d = np.abs(gpu[..., :3].astype(np.float64) - ref[..., :3].astype(np.float64))
+    assert np.sqrt(np.mean(d * d)) < 1e-4 and (d.max(-1) > 1e-5).sum() <= max(1, int(1e-5 * d[..., 0].size))
+    if flags & 8:
+        assert s.counters() == st
+    return gpu, st
+
+
+@pytest.mark.parametrize("size", [(250, 130), (17, 16), (16, 33), (641, 479)])
+def test_ragged_frame_sizes(size, nthreads):
+    w, h = size
+    sc = scenes.get("tiny")
+    with driver.Session(w, h, device=0) as s:
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        frame_equal(s, orc, sc)
+        # resize below 16 is ignored (Renderer.cpp:200), a real resize reallocates
+        s.resize(8, 8)
+        assert (s.width, s.height) == (w, h)
+        s.resize(96, 40)
+        frame_equal(s, orc, sc)
+
+
+def write_mesh(tmp, name, mesh):
+    return scenes._write_mesh(str(tmp), name, mesh, [((0.8, 0.6, 0.4), None)])
+
+
+def test_max_instances_single_leaf_and_big_leaf(tmp_path, nthreads):
+    # mesh 0: one triangle (root is a leaf: tested with no box test, never culled)
+    # mesh 1: 200 identical triangles -> SAH cannot split -> one leaf with 200 triangles (bigLeaf escape)
+    # mesh 2: a small icosphere (ordinary tree)
+    rng = np.random.RandomState(3)
+    one = scenes.Mesh(np.array([[0, 0, 0], [1, 0, 0.1], [0, 1, 0.2]], np.float32), np.zeros((3, 2), np.float32),
+                      np.tile([0, 0, 1], (3, 1)).astype(np.float32), np.array([[0, 1, 2]], np.int32), np.zeros(1, np.int32))
+    # 200 copies of one triangle: all centroids identical -> boundsMax == boundsMin on every axis -> no split
+    pos = np.tile(np.array([[1, 0, 0.3], [-0.5, 0.8660254, -0.1], [-0.5, -0.8660254, -0.2]], np.float32), (200, 1))
+    fan = scenes.Mesh(pos, np.zeros((600, 2), np.float32), np.tile([0, 0, 1], (600, 1)).astype(np.float32),
+                      np.arange(600, dtype=np.int32).reshape(200, 3), np.zeros(200, np.int32))
+    ico = scenes._icosphere(2, 0.8)
+    paths = [write_mesh(tmp_path, "one", one), write_mesh(tmp_path, "fan", fan), write_mesh(tmp_path, "ico", ico)]
+    sky = str(tmp_path / "sky.ppm")
+    scenes.write_ppm(sky, scenes._skybox(64, 32))
+    insts = []
+    for k in range(401):       # Renderer::MaxNumInstances (Renderer.hpp:16); > 64 exercises the candidate chunks
+        t = (float((k % 21) - 10) * 2.2, float((k // 21) - 9) * 2.2, -float(k % 7))
+        insts.append(scenes.Instance(k % 3, 0xFFFF, scenes._trs(0.5 + (k % 5) * 0.2, (0.3, 1.0, 0.2), 0.37 * k, t)))
+    sc = scenes.Scene("edge-401", str(tmp_path), sky, paths, insts, (0.0, 0.0, 40.0), (0.0, 0.0, -1.0))
+    with driver.Session(320, 200, device=0) as s:
+        s.load_scene(sc)
+        a = s.arenas()
+        assert len(a["instances"]) == 401
+        nodes = a["nodes"]
+        assert (nodes["triCount"] >= 128).any() and nodes["triCount"][a["roots"][0]] == 1
+        orc = oracle_lib.Oracle(a, nthreads=nthreads)
+        gpu, st = frame_equal(s, orc, sc)
+        assert st["hits"] > 1000 and st["traversals"] == st["rays"] * 401
+        iv, ip, pos_ = s.camera()
+        o, d = seeded_rays(a, pos_, 16384, seed=5)
+        got = s.query_hits(o, d)
+        ref, hst = orc.closest_hits(o, d)
+        assert got.tobytes() == ref.tobytes() and s.counters() == hst
+        # a 402nd instance is refused (the reference exits, Renderer.cpp:229)
+        p, keep = _lib.fptr(np.eye(4, dtype=np.float32))
+        assert s.h.crth_register_instance(0, 0xFFFF, p) == 0xFFFFFFFF
+        assert s.h.crth_last_error() == -3
+
+
+def test_partial_instance_update_and_material_override(nthreads):
+    sc = scenes.get("tiny")
+    with driver.Session(160, 96, device=0) as s:
+        s.load_scene(sc)
+        s.render(postprocess=False)
+        before = s.output().copy()
+        m = sc.instances[1].matrix.copy(); m[3, :3] += np.array([1.5, -0.5, 0.25], np.float32)
+        p, keep = _lib.fptr(m)
+        s.h.crth_set_mesh_matrix(1, p)                 # dirty range -> partial upload on the next Render (Renderer.cpp:288-320)
+        s.h.crth_set_instance_material(0, 0)           # NoneMaterial: default material 0
+        s.render(postprocess=False)
+        after = s.output()
+        assert not np.array_equal(before, after)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        ref, _ = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
+        assert np.array_equal(bits(after), bits(ref))
+
+
+def test_upload_errors_are_codes_not_crashes():
+    hip = _lib.hip()
+    sc = scenes.get("tiny")
+    with driver.Session(64, 48, device=0) as s:
+        s.load_scene(sc)
+        buf = np.zeros(1024, np.uint8)
+        assert hip.crt_upload_triangles(buf.ctypes.data, 0, 81) == -2                       # not a multiple of 80
+        assert hip.crt_upload_triangles(buf.ctypes.data, 80 * 2400000, 80) == -3             # beyond the pool
+        assert hip.crt_upload_materials(buf.ctypes.data, 250, 10) == -3
+        assert hip.crt_upload_texture_table(buf.ctypes.data, 33) == -3
+        assert hip.crt_upload_instances(None, 0, 1) == -2
+        assert hip.crt_upload_bvh_roots(buf.ctypes.data, 127, 2) == -3
+        assert hip.crt_set_row_bands(8, 0, 1) == -2 and hip.crt_set_row_bands(16, 2, 2) == -2
+        assert hip.crt_read_output(buf.ctypes.data, 5) == -2
+        bad = np.full(2, 0xFFFF, np.uint16)
+        inst = np.zeros(1, _lib.INSTANCE_DTYPE); inst["meshIndex"] = 500
+        assert hip.crt_upload_instances(inst.ctypes.data, 0, 1) == -2                        # mesh index out of range
+        # a cyclic / out-of-range BVH is rejected at upload and rendering is refused until it is fixed
+        a = s.arenas()
+        nodes = a["nodes"].copy()
+        good = nodes.copy()
+        inner = np.where(nodes["triCount"] == 0)[0]
+        nodes["leftFirst"][inner[3]] = inner[0]                                              # child before parent: cycle
+        assert hip.crt_upload_bvh_nodes(nodes.ctypes.data, 0, nodes.nbytes) == -2
+        args, iv, ip = s.trace_args()
+        fp = C.POINTER(C.c_float)
+        assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), 0) == -2
+        assert hip.crt_upload_bvh_nodes(good.ctypes.data, 0, good.nbytes) == 0
+        assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), 0) == 0
