@@ -73,8 +73,11 @@ struct CrtFrame {
     int tilesX;               // ceil(width / 16)
     int ownedTileRows;        // 16-row tile rows this rank renders
     int gridBlocks;           // ceil(ownedTileRows / 8) * 8 * tilesX
-    int tileRowsPerBand;      // bandRows / 16
+    int tileRowsPerBand;      // bandRows / 8
     int rank, nRanks;
+    int slotsPerXcd;          // ceil(ownedTileRows / 8) * tilesX: tiles in each XCD's list
+    const uint32_t* order;    // per-XCD dispatch order (slot -> tile of that XCD's list), heaviest first; see crt_order_kernel
+    uint32_t* cost;           // per tile: shader cycles the wave spent on it this frame (feeds the next frame's order)
 };
 
 struct v3 { float x, y, z; };

@@ -54,13 +54,20 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
 // tile rows left to right -- neighbouring tiles share BVH subtrees in its L2 -- while the eight XCDs
 // interleave row by row, which keeps them equally loaded when geometry is concentrated in one part
 // of the frame (a contiguous slab per XCD left most XCDs idle: ~1.2 resident waves/SIMD measured).
-__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py)
+// `slotOut` receives this workgroup's index into the per-tile cost array (or -1).
+__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, int* slotOut = nullptr)
 {
     const int b = blockIdx.x;
-    const int slot = b >> 3;
+    const int xcd = b & 7;
+    int slot = b >> 3;
+    // Feedback scheduling: each XCD's tiles are launched heaviest-first, by the cycles the same tile cost in the
+    // previous frame (crt_order_kernel). Nothing is cached or skipped -- only the launch order changes -- and the
+    // long-running tiles no longer start late and finish alone (the kernel used to run 0.45 ms full and 0.45 ms of tail).
+    if (F.order) slot = (int)F.order[xcd * F.slotsPerXcd + slot];
+    if (slotOut) *slotOut = xcd * F.slotsPerXcd + slot;
     const int round = slot / F.tilesX;
     const int tx = slot - round * F.tilesX;
-    const int k = round * 8 + (b & 7);                 // index among the tile rows this rank owns
+    const int k = round * 8 + xcd;                     // index among the tile rows this rank owns
     if (k >= F.ownedTileRows) return false;
     const int bandK = k / F.tileRowsPerBand;
     const int tileRow = (F.rank + bandK * F.nRanks) * F.tileRowsPerBand + (k - bandK * F.tileRowsPerBand);
@@ -70,6 +77,48 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py)
     px = tx * CRT_TILE + lx;
     py = tileRow * CRT_TILE + ly;
     return px < F.width && py < F.height;
+}
+
+// Builds the next frame's launch order: one workgroup per XCD list, counting sort of the tiles by this frame's
+// cost, descending. 1024 linear bins up to the list's maximum; ties keep no particular order (irrelevant).
+__global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int slotsPerXcd)
+{
+    __shared__ uint32_t s_bins[1024];
+    __shared__ uint32_t s_max;
+    const int x = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* c = cost + (size_t)x * slotsPerXcd;
+    uint32_t* o = order + (size_t)x * slotsPerXcd;
+    s_bins[tid] = 0;
+    if (tid == 0) s_max = 1;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int i = tid; i < slotsPerXcd; i += 1024) m = c[i] > m ? c[i] : m;
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t mx = s_max;
+    const float scale = 1023.0f / (float)mx;
+    for (int i = tid; i < slotsPerXcd; i += 1024) {
+        int bin = 1023 - (int)((float)c[i] * scale);     // heaviest -> bin 0
+        bin = bin < 0 ? 0 : (bin > 1023 ? 1023 : bin);
+        atomicAdd(&s_bins[bin], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {                                      // exclusive scan (1024 adds: negligible next to the frame)
+        uint32_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint32_t n = s_bins[i]; s_bins[i] = run; run += n; }
+    }
+    __syncthreads();
+    for (int i = tid; i < slotsPerXcd; i += 1024) {
+        int bin = 1023 - (int)((float)c[i] * scale);
+        bin = bin < 0 ? 0 : (bin > 1023 ? 1023 : bin);
+        o[atomicAdd(&s_bins[bin], 1u)] = (uint32_t)i;
+    }
+}
+
+__global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, int slotsPerXcd, int total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) order[i] = (uint32_t)(i % slotsPerXcd);
 }
 
 // kernel Trace (kernel_main.cl:164-275) with RayGen (kernel_main.cl:277-287) fused: the ray
@@ -85,8 +134,9 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
     if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
-    int px, py;
-    const bool active = lane_pixel(F, px, py);
+    int px, py, costSlot = -1;
+    const unsigned long long tc0 = F.cost ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool active = lane_pixel(F, px, py, &costSlot);
     if (active) {
         PathState ps;
         ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
@@ -101,6 +151,10 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
             if (!cont) break;
         }
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    if (F.cost && costSlot >= 0) {      // per-tile cost of this frame (wave-uniform value, one store)
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - tc0;
+        if ((threadIdx.x & 63) == 0) F.cost[costSlot] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
     }
     if (COUNT) flush_counters(lc, counters);
     if (STAMP) {
@@ -359,6 +413,7 @@ struct State {
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
+    uint32_t* tileOrder[2] = { nullptr, nullptr }; uint32_t* tileCost = nullptr; size_t orderCap = 0; int orderCur = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 }; int feedback = 1;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
@@ -396,6 +451,8 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
     F.tilesX = (g.width + CRT_TILE - 1) / CRT_TILE;
     F.ownedTileRows = owned_tile_rows();
     F.gridBlocks = ((F.ownedTileRows + 7) / 8) * 8 * F.tilesX;
+    F.slotsPerXcd = F.gridBlocks / 8;
+    F.order = nullptr; F.cost = nullptr;
     F.tileRowsPerBand = g.bandRows / CRT_TILE;
     F.rank = g.rank; F.nRanks = g.nRanks;
 }
@@ -591,6 +648,7 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
     g.numCUs = prop.multiProcessorCount;
     { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); g.wavefront = (e && strcmp(e, "wavefront") == 0); }  // default: tile kernel (faster)
+    { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.rootRefs, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
@@ -615,7 +673,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.tileOrder[0], g.tileOrder[1], g.tileCost };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -761,6 +819,27 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     CrtDevScene S; fill_scene(S, args->numMeshes);
     if (F.gridBlocks == 0) return CRT_OK;
     const unsigned grid = (unsigned)F.gridBlocks;
+    // feedback launch order (megakernel only): buffers follow the frame geometry; a change resets to identity order
+    const bool useOrder = g.feedback && !g.persistent && !g.wavefront;
+    if (useOrder) {
+        const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
+        if ((size_t)F.gridBlocks > g.orderCap) {
+            for (int i = 0; i < 2; ++i) { if (g.tileOrder[i]) (void)hipFree(g.tileOrder[i]); g.tileOrder[i] = nullptr; }
+            if (g.tileCost) (void)hipFree(g.tileCost);
+            g.tileCost = nullptr; g.orderCap = 0;
+            HIPCHK(hipMalloc(&g.tileOrder[0], sizeof(uint32_t) * (size_t)F.gridBlocks));
+            HIPCHK(hipMalloc(&g.tileOrder[1], sizeof(uint32_t) * (size_t)F.gridBlocks));
+            HIPCHK(hipMalloc(&g.tileCost, sizeof(uint32_t) * (size_t)F.gridBlocks));
+            g.orderCap = (size_t)F.gridBlocks; g.orderSlots = -1;
+        }
+        if (g.orderSlots != F.slotsPerXcd || memcmp(key, g.orderKey, sizeof key) != 0) {
+            crt_identity_order_kernel<<<(F.gridBlocks + 255) / 256, 256, 0, g.stream>>>(g.tileOrder[g.orderCur], F.slotsPerXcd, F.gridBlocks);
+            HIPCHK(hipGetLastError());
+            g.orderSlots = F.slotsPerXcd; memcpy(g.orderKey, key, sizeof key);
+        }
+        HIPCHK(hipMemsetAsync(g.tileCost, 0, sizeof(uint32_t) * (size_t)F.gridBlocks, g.stream));
+        F.order = g.tileOrder[g.orderCur]; F.cost = g.tileCost;
+    }
 
     HIPCHK(hipEventRecord(g.ev[0], g.stream));
     if (flags & CRT_RENDER_WRITE_RAYS) {
@@ -821,6 +900,11 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(g.ev[2], g.stream));
+    if (useOrder) {   // next frame's order from this frame's costs (outside the Trace event pair, inside the frame)
+        crt_order_kernel<<<8, 1024, 0, g.stream>>>(g.tileCost, g.tileOrder[g.orderCur ^ 1], F.slotsPerXcd);
+        HIPCHK(hipGetLastError());
+        g.orderCur ^= 1;
+    }
     if (flags & CRT_RENDER_POSTPROCESS) {
         crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, g.stream>>>(F, g.out);
         HIPCHK(hipGetLastError());
