@@ -46,6 +46,7 @@
 #define CRT_STACK_DECL(name) __shared__ uint32_t name##_lds[CRT_LDS_SLOTS * CRT_BLOCK]; uint32_t spill[CRT_STACK_DEPTH - CRT_LDS_SLOTS]; uint32_t* stack = name##_lds + threadIdx.x
 #define CRT_STACK_WRITE(slot, v) do { const int s_ = (slot) & (CRT_STACK_DEPTH - 1); if (s_ < CRT_LDS_SLOTS) stack[s_ * CRT_BLOCK] = (v); else spill[s_ - CRT_LDS_SLOTS] = (v); } while (0)
 #define CRT_STACK_READ(slot) ((((slot) & (CRT_STACK_DEPTH - 1)) < CRT_LDS_SLOTS) ? stack[((slot) & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] : spill[((slot) & (CRT_STACK_DEPTH - 1)) - CRT_LDS_SLOTS])
+#define CRT_MAX_SPLIT 96   // per XCD and frame: heaviest tiles traced as four 4x4-pixel waves instead of one 8x8 wave
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 
 struct CrtDevScene {
@@ -76,7 +77,9 @@ struct CrtFrame {
     int tileRowsPerBand;      // bandRows / 8
     int rank, nRanks;
     int slotsPerXcd;          // ceil(ownedTileRows / 8) * tilesX: tiles in each XCD's list
-    const uint32_t* order;    // per-XCD dispatch order (slot -> tile of that XCD's list), heaviest first; see crt_order_kernel
+    const uint32_t* order;    // per-XCD dispatch list, heaviest first: slot | quadrant << 28 | split << 31; see crt_order_kernel
+    const uint32_t* listLen;  // entries in each XCD's list (tiles + 3 extra entries per split tile)
+    int listCap;              // capacity of one XCD's list = slotsPerXcd + 3 * CRT_MAX_SPLIT
     uint32_t* cost;           // per tile: shader cycles the wave spent on it this frame (feeds the next frame's order)
 };
 
@@ -205,129 +208,178 @@ __device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
     return r;
 }
 
-// The instance loop + IntersectBVH of kernel_main.cl:124-160,198-217 as ONE per-lane state machine.
+// ------------------------------------------------------------------------------------------------
+// Per-lane traversal state machine: the instance loop + IntersectBVH of kernel_main.cl:124-160,198-217.
 //
-// Upstream (and a literal port) runs `for instance { traverse }` in lock-step: a wave pays, for every
-// instance, the slowest lane's traversal (sum over instances of max over lanes). Here every lane walks
-// its own ascending list of candidate instances and its own traversal; a lane that finishes an instance
-// moves on to its next candidate while its neighbours are still inside another one (max over lanes of
-// the per-lane sum). Per ray the sequence of instances, node visits, triangle tests and the running
-// best t are exactly upstream's, so results are bit-identical.
-//
-//  1. candidate mask: a wave-uniform pass over the instance bounds (scalar loads) sets bit k when the
-//     ray cannot be proven to miss instance k's bounding sphere (conservative; NaN -> candidate).
-//     A culled instance costs upstream exactly one pop and one inner visit and changes nothing,
-//     which is what the counters record for it.
-//  2. unified loop: [enter next candidate] -> [descend inner nodes] -> [leaf triangles, pop].
-// The traversal stack lives in LDS (32 slots x 64 lanes x 4 B = 8 KiB per wave; slot s of this lane at
-// stack[s * 64], conflict-free); slot indices wrap modulo 32 where upstream would overflow its array.
+// Upstream (and a literal port) runs `for instance { while pop { descend } }` in lock-step: a wave pays, for
+// every instance, the slowest lane's traversal, and every lane waits for its neighbours' whole descents. Here
+// every lane owns a `Traversal`: its own ascending list of candidate instances and its own position in the tree,
+// advanced by three step kinds -- enter(next candidate), inner(one child pair), leaf(its triangles, then pop).
+// Per ray the sequence of instances, node visits, triangle tests and the running best t is exactly upstream's,
+// so results are bit-identical; only the interleaving between lanes differs.
+// The stack lives in LDS/scratch (CRT_STACK_*); slot indices wrap modulo 32 where upstream's array would overflow.
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+struct Traversal {
+    v3 mo, md, inv;               // ray in the current instance's object space (direction not renormalised, hazard H6)
+    Triout tr;                    // running best of the current instance (kernel_main.cl:200-202)
+    int sp, prot, inters;         // stack pointer, pop counter (kernel_main.cl:131), OR of the `passed` flags
+    uint32_t ref, curInst;
+    bool active;                  // inside an instance
+
+    __device__ __forceinline__ void reset()
+    {
+        mo = mk3(0.f, 0.f, 0.f); md = mo; inv = mo;
+        tr.t = 0.f; tr.u = 0.f; tr.v = 0.f; tr.tri = 0;
+        sp = 0; prot = 0; inters = 0; ref = 0; curInst = 0; active = false;
+    }
+    __device__ __forceinline__ bool at_inner() const { return active && !(ref & CRT_LEAF_BIT); }
+    __device__ __forceinline__ bool at_leaf() const { return active && (ref & CRT_LEAF_BIT); }
+
+    // ends the current instance: keep the hit if any triangle passed (kernel_main.cl:210-216)
+    __device__ __forceinline__ void finish(Closest& c)
+    {
+        if (inters) { c.hitInstance = (int)curInst; c.hit = tr; c.distance = tr.t; c.anyHit = 1; }
+        active = false;
+    }
+    // `while (currentNodeIndex > 0 && protection++ < 250) node = stack[--currentNodeIndex]` (kernel_main.cl:131-133)
+    __device__ __forceinline__ void pop_next(uint32_t* stack, uint32_t* spill, Closest& c, LaneCounters& lc)
+    {
+        if (sp > 0) {
+            if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; finish(c); }
+            else { if (COUNT) lc.pops++; --sp; ref = CRT_STACK_READ(sp); }
+        } else finish(c);
+    }
+    // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root
+    __device__ __forceinline__ void enter(const CrtDevScene& S, uint32_t inst, v3 o, v3 d, float bestSoFar, LaneCounters& lc)
+    {
+        curInst = inst;
+        const CrtDevInstance* ip = S.devInstances + inst;
+        CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
+        mo = xform_xyz(I, o.x, o.y, o.z, 1.0f);
+        md = xform_xyz(I, d.x, d.y, d.z, 0.0f);
+        inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);       // native_recip pinned to IEEE
+        tr.t = bestSoFar; tr.tri = 0; tr.u = 0.0f; tr.v = 0.0f;
+        ref = __float_as_uint(I.r0.w);                           // the root is popped at once: sp 1 -> 0, protection 0 -> 1
+        sp = 0; prot = 1; inters = 0; active = true;
+        if (COUNT) { lc.traversals++; lc.pops++; }
+    }
+    // kernel_main.cl:142-157: fetch the child pair, two slab tests, near child first, far child pushed
+    __device__ __forceinline__ void inner(const CrtDevScene& S, uint32_t* stack, uint32_t* spill, Closest& c, LaneCounters& lc)
+    {
+        const float4* p = S.pairs + (size_t)ref * 4;
+        const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+        if (COUNT) lc.innerVisits++;
+        float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
+        float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
+        uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
+        if (dist1 > dist2) {
+            float tf = dist1; dist1 = dist2; dist2 = tf;
+            uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
+        }
+        if (dist1 == 1e30f) pop_next(stack, spill, c, lc);
+        else {
+            ref = nearRef;
+            if (dist2 != 1e30f) {
+                if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
+                CRT_STACK_WRITE(sp, farRef);
+                sp++;
+                if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
+            }
+        }
+    }
+    // kernel_main.cl:135-140: every triangle of the leaf, then the next pop
+    __device__ __forceinline__ void leaf(const CrtDevScene& S, uint32_t* stack, uint32_t* spill, Closest& c, LaneCounters& lc)
+    {
+        const uint32_t first = ref & 0x00FFFFFFu;
+        uint32_t n = (ref >> 24) & 0x7Fu;
+        if (n == 0) n = S.bigLeaf[first];
+        for (uint32_t i = first, end = first + n; i < end; ++i) {
+            if (COUNT) lc.triTests++;
+            inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
+        }
+        pop_next(stack, spill, c, lc);
+    }
+};
+
+// Conservative candidate mask for instances [base, base + cnt): bit k is cleared only when the ray provably misses
+// instance base+k's bounding sphere (any NaN -> candidate). A culled instance costs upstream exactly one pop and one
+// inner visit and changes nothing, which is what the counters record for it. Wave-uniform loop, scalar loads.
+template <bool COUNT>
+__device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& S, v3 o, v3 d, uint32_t base, uint32_t cnt, LaneCounters& lc)
+{
+    const float dd = dot3(d, d);
+    unsigned long long cand = 0;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const float4 bs = S.instBounds[base + k];
+        const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);
+        const float oc2 = dot3(oc, oc), b = dot3(oc, d);
+        const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2;       // 1 % on the radius + slack growing with distance
+        const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
+        if (!cull) cand |= 1ull << k;
+    }
+    if (COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(cand); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
+    return cand;
+}
+
+// Packets with at most this many lanes still working advance every lane through every step kind each trip
+// (latency of the longest ray matters, issue slots do not); larger packets vote for one step kind per trip.
+#ifndef CRT_SMALL_PACKET
+#define CRT_SMALL_PACKET 16
+#endif
+
+// Closest hit of one ray per lane over all instances (kernel_main.cl:198-217), driven in flat trips:
+//  * large packets: exactly ONE step kind runs per trip, the one most lanes are waiting for (three ballots +
+//    popcounts), so each section's code is issued for many lanes and no lane waits for a neighbour's whole descent.
+//    Measured on multi-1M: the nested descend-then-leaf loops needed 2.66 M wave-trips at 16 active lanes and 1979
+//    trips for a tile whose longest ray has 361 visits; voted trips need 1.64 M at 26 lanes and 738.
+//  * small packets (quadrant waves of split tiles, tails): all three kinds run, a lane may enter, visit and test
+//    a leaf in the same trip.
 template <bool COUNT, bool ITERS = false>
 __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, uint32_t* stack, uint32_t* spill, LaneCounters& lc)
 {
     Closest c;
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
     c.hit.t = 0.0f; c.hit.u = 0.0f; c.hit.v = 0.0f; c.hit.tri = 0;
-    const float dd = dot3(d, d);
+    Traversal<COUNT> T; T.reset();
 
     for (uint32_t base = 0; base < S.numInstances; base += 64) {
         const uint32_t cnt = (S.numInstances - base) < 64u ? (S.numInstances - base) : 64u;
-        unsigned long long cand = 0;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            const float4 bs = S.instBounds[base + k];                 // uniform index -> scalar load
-            const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);
-            const float oc2 = dot3(oc, oc), b = dot3(oc, d);
-            const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2;     // 1 % on the radius + slack growing with distance
-            const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
-            if (!cull) cand |= 1ull << k;
-        }
-        if (COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(cand); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
-
-        bool active = false;
-        v3 mo = mk3(0.f, 0.f, 0.f), md = mo, inv = mo;
-        Triout tr; tr.t = 0.f; tr.u = 0.f; tr.v = 0.f; tr.tri = 0;
-        int sp = 0, prot = 0, inters = 0;
-        uint32_t ref = 0, curInst = 0;
-
-        // ends the current traversal: keep the hit if any triangle passed (kernel_main.cl:210-216)
-#define CRT_FINISH() do { if (inters) { c.hitInstance = (int)curInst; c.hit = tr; c.distance = tr.t; c.anyHit = 1; } active = false; } while (0)
-        // `while (currentNodeIndex > 0 && protection++ < 250) node = stack[--currentNodeIndex]` (kernel_main.cl:131-133)
-#define CRT_POP_NEXT() do { \
-            if (sp > 0) { \
-                if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; CRT_FINISH(); } \
-                else { if (COUNT) lc.pops++; --sp; ref = CRT_STACK_READ(sp); } \
-            } else CRT_FINISH(); } while (0)
-
-        // Flat trips with a vote: exactly one step kind (inner node / leaf / enter next instance) runs per
-        // trip, the one most lanes are waiting for. No lane waits for a neighbour's whole descent, so the
-        // number of trips a wave needs approaches its slowest lane's own step count (measured on multi-1M:
-        // the nested descend-then-leaf loops needed 1979 trips for a tile whose longest ray has 361 visits).
+        unsigned long long cand = candidate_mask<COUNT>(S, o, d, base, cnt, lc);
         bool done = false;
         for (;;) {
-            const bool wEnter = !done && !active;
-            const bool wInner = !done && active && !(ref & CRT_LEAF_BIT);
-            const bool wLeaf = !done && active && (ref & CRT_LEAF_BIT);
+            const bool wEnter = !done && !T.active;
+            const bool wInner = !done && T.at_inner();
+            const bool wLeaf = !done && T.at_leaf();
             const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
             if (nE + nI + nL == 0) break;
             if (ITERS) { if (first_active_lane()) lc.pops++; }
-            if (nI > 0 && nI >= nE && nI >= nL) {
-                if (wInner) {
-                    const float4* p = S.pairs + (size_t)ref * 4;
-                    const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
-                    if (COUNT) lc.innerVisits++;
-                    if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
-                    float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
-                    float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
-                    uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
-                    if (dist1 > dist2) {
-                        float tf = dist1; dist1 = dist2; dist2 = tf;
-                        uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
-                    }
-                    if (dist1 == 1e30f) { CRT_POP_NEXT(); }
-                    else {
-                        ref = nearRef;
-                        if (dist2 != 1e30f) {
-                            if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
-                            CRT_STACK_WRITE(sp, farRef);
-                            sp++;
-                            if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
-                        }
-                    }
-                }
-            } else if (nL > 0 && nL >= nE) {
-                if (wLeaf) {
-                    if (ITERS) { if (first_active_lane()) lc.triTests++; }
-                    const uint32_t first = ref & 0x00FFFFFFu;
-                    uint32_t n = (ref >> 24) & 0x7Fu;
-                    if (n == 0) n = S.bigLeaf[first];
-                    for (uint32_t i = first, end = first + n; i < end; ++i) {
-                        if (COUNT) lc.triTests++;
-                        inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
-                    }
-                    CRT_POP_NEXT();
-                }
-            } else {
+            const bool all = (nE + nI + nL) <= (uint32_t)CRT_SMALL_PACKET;
+            const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
+            if (all || (!runI && !runL)) {
                 if (wEnter) {
-                    if (cand == 0) done = true;                            // this lane is finished with the chunk
+                    if (cand == 0) done = true;                    // this lane is finished with the chunk
                     else {
                         if (ITERS) { if (first_active_lane()) lc.traversals++; }
                         const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
                         cand &= cand - 1;
-                        curInst = base + k;
-                        const CrtDevInstance* ip = S.devInstances + curInst;
-                        CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
-                        mo = xform_xyz(I, o.x, o.y, o.z, 1.0f);
-                        md = xform_xyz(I, d.x, d.y, d.z, 0.0f);              // not renormalised (hazard H6)
-                        inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);    // native_recip pinned to IEEE
-                        tr.t = c.distance; tr.tri = 0; tr.u = 0.0f; tr.v = 0.0f;
-                        ref = __float_as_uint(I.r0.w);                       // the root is popped immediately: sp 1 -> 0, protection 0 -> 1
-                        sp = 0; prot = 1; inters = 0; active = true;
-                        if (COUNT) { lc.traversals++; lc.pops++; }
+                        T.enter(S, base + k, o, d, c.distance, lc);
                     }
                 }
             }
+            if (all || runI) {
+                if (!done && T.at_inner()) {
+                    if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
+                    T.inner(S, stack, spill, c, lc);
+                }
+            }
+            if (all || runL) {
+                if (!done && T.at_leaf()) {
+                    if (ITERS) { if (first_active_lane()) lc.triTests++; }
+                    T.leaf(S, stack, spill, c, lc);
+                }
+            }
         }
-#undef CRT_POP_NEXT
-#undef CRT_FINISH
     }
     return c;
 }

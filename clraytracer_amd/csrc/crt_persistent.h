@@ -71,20 +71,9 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void crt_trace_persistent_kernel(CrtD
     PathState ps;
     ps.o = mk3(0.f, 0.f, 0.f); ps.d = ps.o; ps.result = ps.o; ps.energy = 0.f;
     Closest c; c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0; c.hit.t = 0.f; c.hit.u = 0.f; c.hit.v = 0.f; c.hit.tri = 0;
-    // ---- per-lane traversal state ----
+    // ---- per-lane traversal state (shared with the tile kernel: crt_device.h) ----
     uint32_t base = 0; unsigned long long cand = 0;
-    bool active = false;
-    v3 mo = mk3(0.f, 0.f, 0.f), md = mo, inv = mo;
-    Triout tr; tr.t = 0.f; tr.u = 0.f; tr.v = 0.f; tr.tri = 0;
-    int sp = 0, prot = 0, inters = 0;
-    uint32_t ref = 0, curInst = 0;
-
-#define CRT_FINISH() do { if (inters) { c.hitInstance = (int)curInst; c.hit = tr; c.distance = tr.t; c.anyHit = 1; } active = false; } while (0)
-#define CRT_POP_NEXT() do { \
-        if (sp > 0) { \
-            if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; CRT_FINISH(); } \
-            else { if (COUNT) lc.pops++; --sp; ref = CRT_STACK_READ(sp); } \
-        } else CRT_FINISH(); } while (0)
+    Traversal<COUNT> T; T.reset();
 
     for (;;) {
         // =====================================================================================
@@ -176,22 +165,10 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void crt_trace_persistent_kernel(CrtD
                     for (int off = 32; off > 0; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)ubase, off, 64); ubase = o2 < ubase ? o2 : ubase; }
                     ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ubase);
                     if (state == CRT_ST_NEED_CAND && base == ubase) {
-                        const float dd = dot3(ps.d, ps.d);
                         const uint32_t cnt = (S.numInstances - ubase) < 64u ? (S.numInstances - ubase) : 64u;
-                        unsigned long long m = 0;
-                        if (ubase < S.numInstances) {
-                            for (uint32_t k = 0; k < cnt; ++k) {
-                                const float4 bs = S.instBounds[ubase + k];                 // uniform -> scalar load
-                                const v3 oc = mk3(bs.x - ps.o.x, bs.y - ps.o.y, bs.z - ps.o.z);
-                                const float oc2 = dot3(oc, oc), b = dot3(oc, ps.d);
-                                const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2;
-                                const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
-                                if (!cull) m |= 1ull << k;
-                            }
-                            if (COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(m); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
-                        }
+                        const unsigned long long m = ubase < S.numInstances ? candidate_mask<COUNT>(S, ps.o, ps.d, ubase, cnt, lc) : 0ull;
                         cand = m;
-                        if (m != 0) { state = CRT_ST_TRAVERSE; active = false; }
+                        if (m != 0) { state = CRT_ST_TRAVERSE; T.active = false; }
                         else if (ubase + 64u < S.numInstances) base = ubase + 64u;           // stays NEED_CAND
                         else state = CRT_ST_WAIT_SHADE;                                     // nothing (more) to traverse
                     }
@@ -210,46 +187,16 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void crt_trace_persistent_kernel(CrtD
         // node) keeps running, and are then served together.
         // =====================================================================================
         const bool trav = state == CRT_ST_TRAVERSE;
-        const bool wEnter = trav && !active;
-        const bool wInner = trav && active && !(ref & CRT_LEAF_BIT);
-        const bool wLeaf = trav && active && (ref & CRT_LEAF_BIT);
+        const bool wEnter = trav && !T.active;
+        const bool wInner = trav && T.at_inner();
+        const bool wLeaf = trav && T.at_leaf();
         const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
         if (nI > 0 && nI >= nE && nI >= nL) {
             if (DIAG) { if (lane == 0) { dg[2]++; dg[3] += nI; } }
-            if (wInner) {
-                const float4* p = S.pairs + (size_t)ref * 4;
-                const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
-                if (COUNT) lc.innerVisits++;
-                float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
-                float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
-                uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
-                if (dist1 > dist2) {
-                    float tf = dist1; dist1 = dist2; dist2 = tf;
-                    uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
-                }
-                if (dist1 == 1e30f) { CRT_POP_NEXT(); }
-                else {
-                    ref = nearRef;
-                    if (dist2 != 1e30f) {
-                        if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
-                        CRT_STACK_WRITE(sp, farRef);
-                        sp++;
-                        if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
-                    }
-                }
-            }
+            if (wInner) T.inner(S, stack, spill, c, lc);
         } else if (nL > 0 && nL >= nE) {
             if (DIAG) { if (lane == 0) { dg[4]++; dg[5] += nL; } }
-            if (wLeaf) {
-                const uint32_t first = ref & 0x00FFFFFFu;
-                uint32_t n = (ref >> 24) & 0x7Fu;
-                if (n == 0) n = S.bigLeaf[first];
-                for (uint32_t i = first, end = first + n; i < end; ++i) {
-                    if (COUNT) lc.triTests++;
-                    inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
-                }
-                CRT_POP_NEXT();
-            }
+            if (wLeaf) T.leaf(S, stack, spill, c, lc);
         } else if (nE > 0) {
             if (DIAG) { if (lane == 0) { dg[6]++; dg[7] += nE; } }
             if (wEnter) {
@@ -259,22 +206,11 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void crt_trace_persistent_kernel(CrtD
                 } else {
                     const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
                     cand &= cand - 1;
-                    curInst = base + k;
-                    const CrtDevInstance* ip = S.devInstances + curInst;
-                    CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
-                    mo = xform_xyz(I, ps.o.x, ps.o.y, ps.o.z, 1.0f);
-                    md = xform_xyz(I, ps.d.x, ps.d.y, ps.d.z, 0.0f);          // not renormalised (hazard H6)
-                    inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);        // native_recip pinned to IEEE
-                    tr.t = c.distance; tr.tri = 0; tr.u = 0.0f; tr.v = 0.0f;
-                    ref = __float_as_uint(I.r0.w);                           // root popped at once: sp 1 -> 0, protection 0 -> 1
-                    sp = 0; prot = 1; inters = 0; active = true;
-                    if (COUNT) { lc.traversals++; lc.pops++; }
+                    T.enter(S, base + k, ps.o, ps.d, c.distance, lc);
                 }
             }
         }
     }
-#undef CRT_POP_NEXT
-#undef CRT_FINISH
     if (COUNT) flush_counters(lc, counters);
     if (DIAG) {
         const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1rt = __builtin_amdgcn_s_memrealtime();

@@ -60,10 +60,17 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
     const int b = blockIdx.x;
     const int xcd = b & 7;
     int slot = b >> 3;
-    // Feedback scheduling: each XCD's tiles are launched heaviest-first, by the cycles the same tile cost in the
-    // previous frame (crt_order_kernel). Nothing is cached or skipped -- only the launch order changes -- and the
-    // long-running tiles no longer start late and finish alone (the kernel used to run 0.45 ms full and 0.45 ms of tail).
-    if (F.order) slot = (int)F.order[xcd * F.slotsPerXcd + slot];
+    int quadrant = -1;
+    // Feedback scheduling (crt_order_kernel): each XCD's tiles are launched heaviest-first, by the cycles the same
+    // tile cost in the previous frame, and the very heaviest are traced by four waves of one 4x4 quadrant each, so
+    // that no single wave's serial chain outlasts the rest of the frame. Nothing is cached or skipped -- only the
+    // launch order and the wave shape change. (Before: 0.45 ms with the machine full + 0.45 ms of tail.)
+    if (F.order) {
+        if ((uint32_t)slot >= F.listLen[xcd]) { if (slotOut) *slotOut = -1; return false; }
+        const uint32_t e = F.order[xcd * F.listCap + slot];
+        slot = (int)(e & 0x0FFFFFFFu);
+        if (e & 0x80000000u) quadrant = (int)((e >> 28) & 3u);
+    } else if (slot >= F.slotsPerXcd) { if (slotOut) *slotOut = -1; return false; }
     if (slotOut) *slotOut = xcd * F.slotsPerXcd + slot;
     const int round = slot / F.tilesX;
     const int tx = slot - round * F.tilesX;
@@ -72,6 +79,7 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
     const int bandK = k / F.tileRowsPerBand;
     const int tileRow = (F.rank + bandK * F.nRanks) * F.tileRowsPerBand + (k - bandK * F.tileRowsPerBand);
     const int lane = threadIdx.x & 63;
+    if (quadrant >= 0 && (lane >> 4) != quadrant) return false;   // Morton order: lanes 16q..16q+15 are one 4x4 quadrant
     const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
     const int ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
     px = tx * CRT_TILE + lx;
@@ -79,15 +87,17 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
     return px < F.width && py < F.height;
 }
 
-// Builds the next frame's launch order: one workgroup per XCD list, counting sort of the tiles by this frame's
-// cost, descending. 1024 linear bins up to the list's maximum; ties keep no particular order (irrelevant).
-__global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int slotsPerXcd)
+// Builds the next frame's launch lists: one workgroup per XCD, counting sort of that XCD's tiles by this frame's
+// cost, descending (1024 linear bins up to the list's maximum). The tiles that cost at least half the maximum
+// (at most CRT_MAX_SPLIT) are emitted as four quadrant entries each and come first.
+__global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
+                                                       uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap)
 {
     __shared__ uint32_t s_bins[1024];
-    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_max, s_nSplit;
     const int x = blockIdx.x, tid = threadIdx.x;
     const uint32_t* c = cost + (size_t)x * slotsPerXcd;
-    uint32_t* o = order + (size_t)x * slotsPerXcd;
+    uint32_t* o = order + (size_t)x * listCap;
     s_bins[tid] = 0;
     if (tid == 0) s_max = 1;
     __syncthreads();
@@ -95,8 +105,7 @@ __global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restr
     for (int i = tid; i < slotsPerXcd; i += 1024) m = c[i] > m ? c[i] : m;
     atomicMax(&s_max, m);
     __syncthreads();
-    const uint32_t mx = s_max;
-    const float scale = 1023.0f / (float)mx;
+    const float scale = 1023.0f / (float)s_max;
     for (int i = tid; i < slotsPerXcd; i += 1024) {
         int bin = 1023 - (int)((float)c[i] * scale);     // heaviest -> bin 0
         bin = bin < 0 ? 0 : (bin > 1023 ? 1023 : bin);
@@ -104,21 +113,28 @@ __global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restr
     }
     __syncthreads();
     if (tid == 0) {                                      // exclusive scan (1024 adds: negligible next to the frame)
-        uint32_t run = 0;
-        for (int i = 0; i < 1024; ++i) { const uint32_t n = s_bins[i]; s_bins[i] = run; run += n; }
+        uint32_t run = 0, heavy = 0;
+        for (int i = 0; i < 1024; ++i) { const uint32_t n = s_bins[i]; s_bins[i] = run; run += n; if (i == 511) heavy = run; }
+        // bins 0..511 hold cost > max/2; a frame of equal tiles (nothing stands out) splits nothing
+        s_nSplit = (heavy * 8u > (uint32_t)slotsPerXcd) ? 0u : (heavy < (uint32_t)CRT_MAX_SPLIT ? heavy : (uint32_t)CRT_MAX_SPLIT);
+        listLen[x] = (uint32_t)slotsPerXcd + 3u * s_nSplit;
     }
     __syncthreads();
+    const uint32_t nSplit = s_nSplit;
     for (int i = tid; i < slotsPerXcd; i += 1024) {
         int bin = 1023 - (int)((float)c[i] * scale);
         bin = bin < 0 ? 0 : (bin > 1023 ? 1023 : bin);
-        o[atomicAdd(&s_bins[bin], 1u)] = (uint32_t)i;
+        const uint32_t pos = atomicAdd(&s_bins[bin], 1u);
+        if (pos < nSplit) { for (uint32_t q = 0; q < 4; ++q) o[4 * pos + q] = (uint32_t)i | (q << 28) | 0x80000000u; }
+        else o[3 * nSplit + pos] = (uint32_t)i;
     }
 }
 
-__global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, int slotsPerXcd, int total)
+__global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) order[i] = (uint32_t)(i % slotsPerXcd);
+    if (i < 8) listLen[i] = (uint32_t)slotsPerXcd;
+    if (i < 8 * slotsPerXcd) order[(i / slotsPerXcd) * listCap + (i % slotsPerXcd)] = (uint32_t)(i % slotsPerXcd);
 }
 
 // kernel Trace (kernel_main.cl:164-275) with RayGen (kernel_main.cl:277-287) fused: the ray
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
     }
     if (F.cost && costSlot >= 0) {      // per-tile cost of this frame (wave-uniform value, one store)
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - tc0;
-        if ((threadIdx.x & 63) == 0) F.cost[costSlot] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&F.cost[costSlot], dt > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)dt);   // the four waves of a split tile add up
     }
     if (COUNT) flush_counters(lc, counters);
     if (STAMP) {
@@ -413,7 +429,7 @@ struct State {
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
-    uint32_t* tileOrder[2] = { nullptr, nullptr }; uint32_t* tileCost = nullptr; size_t orderCap = 0; int orderCur = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 }; int feedback = 1;
+    uint32_t* tileOrder[2] = { nullptr, nullptr }; uint32_t* tileLen[2] = { nullptr, nullptr }; uint32_t* tileCost = nullptr; size_t orderCap = 0; int orderCur = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 }; int feedback = 1;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
@@ -452,7 +468,7 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
     F.ownedTileRows = owned_tile_rows();
     F.gridBlocks = ((F.ownedTileRows + 7) / 8) * 8 * F.tilesX;
     F.slotsPerXcd = F.gridBlocks / 8;
-    F.order = nullptr; F.cost = nullptr;
+    F.order = nullptr; F.cost = nullptr; F.listLen = nullptr; F.listCap = F.slotsPerXcd;
     F.tileRowsPerBand = g.bandRows / CRT_TILE;
     F.rank = g.rank; F.nRanks = g.nRanks;
 }
@@ -673,7 +689,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.tileOrder[0], g.tileOrder[1], g.tileCost };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.tileOrder[0], g.tileOrder[1], g.tileLen[0], g.tileLen[1], g.tileCost };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -818,27 +834,33 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     CrtFrame F; fill_frame(F, args, invView, invProj);
     CrtDevScene S; fill_scene(S, args->numMeshes);
     if (F.gridBlocks == 0) return CRT_OK;
-    const unsigned grid = (unsigned)F.gridBlocks;
-    // feedback launch order (megakernel only): buffers follow the frame geometry; a change resets to identity order
+    // feedback launch lists (megakernel only): buffers follow the frame geometry; a change resets to identity order
     const bool useOrder = g.feedback && !g.persistent && !g.wavefront;
+    unsigned grid = (unsigned)F.gridBlocks;
     if (useOrder) {
         const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
-        if ((size_t)F.gridBlocks > g.orderCap) {
-            for (int i = 0; i < 2; ++i) { if (g.tileOrder[i]) (void)hipFree(g.tileOrder[i]); g.tileOrder[i] = nullptr; }
+        F.listCap = F.slotsPerXcd + 3 * CRT_MAX_SPLIT;
+        const size_t need = (size_t)8 * (size_t)F.listCap;
+        if (need > g.orderCap) {
+            for (int i = 0; i < 2; ++i) {
+                if (g.tileOrder[i]) (void)hipFree(g.tileOrder[i]);
+                if (g.tileLen[i]) (void)hipFree(g.tileLen[i]);
+                g.tileOrder[i] = nullptr; g.tileLen[i] = nullptr;
+            }
             if (g.tileCost) (void)hipFree(g.tileCost);
             g.tileCost = nullptr; g.orderCap = 0;
-            HIPCHK(hipMalloc(&g.tileOrder[0], sizeof(uint32_t) * (size_t)F.gridBlocks));
-            HIPCHK(hipMalloc(&g.tileOrder[1], sizeof(uint32_t) * (size_t)F.gridBlocks));
-            HIPCHK(hipMalloc(&g.tileCost, sizeof(uint32_t) * (size_t)F.gridBlocks));
-            g.orderCap = (size_t)F.gridBlocks; g.orderSlots = -1;
+            for (int i = 0; i < 2; ++i) { HIPCHK(hipMalloc(&g.tileOrder[i], sizeof(uint32_t) * need)); HIPCHK(hipMalloc(&g.tileLen[i], sizeof(uint32_t) * 8)); }
+            HIPCHK(hipMalloc(&g.tileCost, sizeof(uint32_t) * need));
+            g.orderCap = need; g.orderSlots = -1;
         }
         if (g.orderSlots != F.slotsPerXcd || memcmp(key, g.orderKey, sizeof key) != 0) {
-            crt_identity_order_kernel<<<(F.gridBlocks + 255) / 256, 256, 0, g.stream>>>(g.tileOrder[g.orderCur], F.slotsPerXcd, F.gridBlocks);
+            crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, g.stream>>>(g.tileOrder[g.orderCur], g.tileLen[g.orderCur], F.slotsPerXcd, F.listCap);
             HIPCHK(hipGetLastError());
             g.orderSlots = F.slotsPerXcd; memcpy(g.orderKey, key, sizeof key);
         }
         HIPCHK(hipMemsetAsync(g.tileCost, 0, sizeof(uint32_t) * (size_t)F.gridBlocks, g.stream));
-        F.order = g.tileOrder[g.orderCur]; F.cost = g.tileCost;
+        F.order = g.tileOrder[g.orderCur]; F.listLen = g.tileLen[g.orderCur]; F.cost = g.tileCost;
+        grid = 8u * (unsigned)F.listCap;
     }
 
     HIPCHK(hipEventRecord(g.ev[0], g.stream));
@@ -901,7 +923,7 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(g.ev[2], g.stream));
     if (useOrder) {   // next frame's order from this frame's costs (outside the Trace event pair, inside the frame)
-        crt_order_kernel<<<8, 1024, 0, g.stream>>>(g.tileCost, g.tileOrder[g.orderCur ^ 1], F.slotsPerXcd);
+        crt_order_kernel<<<8, 1024, 0, g.stream>>>(g.tileCost, g.tileOrder[g.orderCur ^ 1], g.tileLen[g.orderCur ^ 1], F.slotsPerXcd, F.listCap);
         HIPCHK(hipGetLastError());
         g.orderCur ^= 1;
     }
