@@ -90,7 +90,7 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
 // Builds the next frame's launch lists: one workgroup per XCD, counting sort of that XCD's tiles by this frame's
 // cost, descending (1024 linear bins up to the list's maximum). The tiles that cost at least half the maximum
 // (at most CRT_MAX_SPLIT) are emitted as four quadrant entries each and come first.
-__global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
+__global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
                                                        uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap)
 {
     __shared__ uint32_t s_bins[1024];
@@ -112,12 +112,23 @@ __global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restr
         atomicAdd(&s_bins[bin], 1u);
     }
     __syncthreads();
-    if (tid == 0) {                                      // exclusive scan (1024 adds: negligible next to the frame)
-        uint32_t run = 0, heavy = 0;
-        for (int i = 0; i < 1024; ++i) { const uint32_t n = s_bins[i]; s_bins[i] = run; run += n; if (i == 511) heavy = run; }
-        // bins 0..511 hold cost > max/2; a frame of equal tiles (nothing stands out) splits nothing
-        s_nSplit = (heavy * 8u > (uint32_t)slotsPerXcd) ? 0u : (heavy < (uint32_t)CRT_MAX_SPLIT ? heavy : (uint32_t)CRT_MAX_SPLIT);
-        listLen[x] = (uint32_t)slotsPerXcd + 3u * s_nSplit;
+    // exclusive scan of the 1024 bins: one bin per thread, wave scans + a scan of the 16 wave totals
+    {
+        const uint32_t n = s_bins[tid];
+        uint32_t incl = n;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if ((tid & 63) >= off) incl += v; }
+        __shared__ uint32_t s_wave[16];
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (tid >> 6); ++w) wbase += s_wave[w];
+        s_bins[tid] = wbase + incl - n;
+        if (tid == 511) {
+            // bins 0..511 hold cost > max/2; a frame of near-equal tiles (nothing stands out) splits nothing
+            const uint32_t heavy = wbase + incl;
+            s_nSplit = (heavy * 8u > (uint32_t)slotsPerXcd) ? 0u : (heavy < (uint32_t)CRT_MAX_SPLIT ? heavy : (uint32_t)CRT_MAX_SPLIT);
+            listLen[x] = (uint32_t)slotsPerXcd + 3u * s_nSplit;
+        }
     }
     __syncthreads();
     const uint32_t nSplit = s_nSplit;
@@ -128,6 +139,8 @@ __global__ __launch_bounds__(1024) void crt_order_kernel(const uint32_t* __restr
         if (pos < nSplit) { for (uint32_t q = 0; q < 4; ++q) o[4 * pos + q] = (uint32_t)i | (q << 28) | 0x80000000u; }
         else o[3 * nSplit + pos] = (uint32_t)i;
     }
+    __syncthreads();
+    for (int i = tid; i < slotsPerXcd; i += 1024) cost[(size_t)x * slotsPerXcd + i] = 0;    // this frame's waves add their cycles
 }
 
 __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap)
@@ -429,7 +442,7 @@ struct State {
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
-    uint32_t* tileOrder[2] = { nullptr, nullptr }; uint32_t* tileLen[2] = { nullptr, nullptr }; uint32_t* tileCost = nullptr; size_t orderCap = 0; int orderCur = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 }; int feedback = 1;
+    uint32_t* tileOrder[2] = { nullptr, nullptr }; uint32_t* tileLen[2] = { nullptr, nullptr }; uint32_t* tileCost = nullptr; size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 }; int feedback = 1;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
@@ -437,7 +450,7 @@ struct State {
     bool sceneValid = true;
     float ms[4] = { 0, 0, 0, 0 };
     bool timed[4] = { false, false, false, false };
-    bool pendingTiming = false; int pendingFlags = 0;
+    bool pendingTiming = false; int pendingFlags = 0; bool evRaygen = false, evPost = false;
     CrtCounters lastCounters;
 };
 State g;
@@ -586,12 +599,14 @@ int rebuild_instance_bounds()
 int collect_timing()
 {
     if (!g.pendingTiming) return CRT_OK;
-    HIPCHK(hipEventSynchronize(g.ev[4]));
+    hipEvent_t traceStart = g.evRaygen ? g.ev[1] : g.ev[0], frameEnd = g.evPost ? g.ev[3] : g.ev[2];
+    HIPCHK(hipEventSynchronize(frameEnd));
     float t = 0;
-    HIPCHK(hipEventElapsedTime(&t, g.ev[0], g.ev[4])); g.ms[0] = t;
-    HIPCHK(hipEventElapsedTime(&t, g.ev[0], g.ev[1])); g.ms[1] = t;
-    HIPCHK(hipEventElapsedTime(&t, g.ev[1], g.ev[2])); g.ms[2] = t;
-    HIPCHK(hipEventElapsedTime(&t, g.ev[2], g.ev[3])); g.ms[3] = t;
+    HIPCHK(hipEventElapsedTime(&t, g.ev[0], frameEnd)); g.ms[0] = t;
+    g.ms[1] = 0.0f; g.ms[3] = 0.0f;
+    if (g.evRaygen) { HIPCHK(hipEventElapsedTime(&t, g.ev[0], g.ev[1])); g.ms[1] = t; }
+    HIPCHK(hipEventElapsedTime(&t, traceStart, g.ev[2])); g.ms[2] = t;
+    if (g.evPost) { HIPCHK(hipEventElapsedTime(&t, g.ev[2], g.ev[3])); g.ms[3] = t; }
     if (g.pendingFlags & CRT_RENDER_COUNTERS) {
         unsigned long long c[12];
         HIPCHK(hipMemcpy(c, g.counters, sizeof c, hipMemcpyDeviceToHost));
@@ -823,6 +838,92 @@ int crt_upload_instances(const void* instances, size_t first, size_t count)
     return rebuild_instance_bounds();
 }
 
+// Feedback launch lists for the megakernel (lane_pixel / crt_order_kernel). Buffers follow the frame geometry; a
+// change of geometry resets to the identity order. Every frame starts by turning the previous frame's per-tile
+// costs into this frame's lists (and zeroing the costs), so the sort is inside the frame but outside the Trace
+// event pair.
+static int prepare_launch_lists(CrtFrame& F, unsigned& grid)
+{
+    const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
+    F.listCap = F.slotsPerXcd + 3 * CRT_MAX_SPLIT;
+    const size_t need = (size_t)8 * (size_t)F.listCap;
+    if (need > g.orderCap) {
+        if (g.tileOrder[0]) (void)hipFree(g.tileOrder[0]);
+        if (g.tileLen[0]) (void)hipFree(g.tileLen[0]);
+        if (g.tileCost) (void)hipFree(g.tileCost);
+        g.tileOrder[0] = nullptr; g.tileLen[0] = nullptr; g.tileCost = nullptr; g.orderCap = 0;
+        HIPCHK(hipMalloc(&g.tileOrder[0], sizeof(uint32_t) * need));
+        HIPCHK(hipMalloc(&g.tileLen[0], sizeof(uint32_t) * 8));
+        HIPCHK(hipMalloc(&g.tileCost, sizeof(uint32_t) * need));
+        g.orderCap = need; g.orderSlots = -1;
+    }
+    if (g.orderSlots != F.slotsPerXcd || memcmp(key, g.orderKey, sizeof key) != 0) {
+        HIPCHK(hipMemsetAsync(g.tileCost, 0, sizeof(uint32_t) * need, g.stream));
+        crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, g.stream>>>(g.tileOrder[0], g.tileLen[0], F.slotsPerXcd, F.listCap);
+        g.orderSlots = F.slotsPerXcd; memcpy(g.orderKey, key, sizeof key);
+    } else {
+        crt_order_kernel<<<8, 1024, 0, g.stream>>>(g.tileCost, g.tileOrder[0], g.tileLen[0], F.slotsPerXcd, F.listCap);
+    }
+    HIPCHK(hipGetLastError());
+    F.order = g.tileOrder[0]; F.listLen = g.tileLen[0]; F.cost = g.tileCost;
+    grid = 8u * (unsigned)F.listCap;
+    return CRT_OK;
+}
+
+// The Trace launch(es) of one frame, by kernel structure (default: megakernel with feedback launch lists).
+static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid)
+{
+    const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
+    if (count) HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
+    if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
+        unsigned waves = grid;
+        if (g.persistent) {
+            const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
+            waves = (unsigned)(g.numCUs * g.wavesPerCU);
+            if (waves > tiles) waves = tiles;
+        }
+        const size_t need = (16 + (size_t)waves * 8) * sizeof(unsigned long long);
+        if (need > g.stampBytes) {
+            if (g.stamps) (void)hipFree(g.stamps);
+            g.stamps = nullptr; g.stampBytes = 0;
+            HIPCHK(hipMalloc(&g.stamps, need));
+            g.stampBytes = need;
+        }
+        g.stampWaves = waves;
+        HIPCHK(hipMemsetAsync(g.stamps, 0, need, g.stream));
+        if (g.persistent) {
+            HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
+            crt_trace_persistent_kernel<false, true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps, g.queues);
+        } else {
+            crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
+        }
+    } else if (g.persistent) {                             // resident waves pulling tiles from per-XCD queues
+        const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
+        unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);
+        if (waves > tiles) waves = tiles;
+        HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
+        if (count) crt_trace_persistent_kernel<true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
+        else crt_trace_persistent_kernel<false><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
+    } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
+        const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
+        const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
+        HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), g.stream));
+        if (count) {
+            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+        } else {
+            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+        }
+    } else if (count) {
+        crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
+    } else {
+        crt_trace_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
+    }
+    HIPCHK(hipGetLastError());
+    return CRT_OK;
+}
+
 int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
@@ -834,107 +935,29 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     CrtFrame F; fill_frame(F, args, invView, invProj);
     CrtDevScene S; fill_scene(S, args->numMeshes);
     if (F.gridBlocks == 0) return CRT_OK;
-    // feedback launch lists (megakernel only): buffers follow the frame geometry; a change resets to identity order
-    const bool useOrder = g.feedback && !g.persistent && !g.wavefront;
     unsigned grid = (unsigned)F.gridBlocks;
-    if (useOrder) {
-        const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
-        F.listCap = F.slotsPerXcd + 3 * CRT_MAX_SPLIT;
-        const size_t need = (size_t)8 * (size_t)F.listCap;
-        if (need > g.orderCap) {
-            for (int i = 0; i < 2; ++i) {
-                if (g.tileOrder[i]) (void)hipFree(g.tileOrder[i]);
-                if (g.tileLen[i]) (void)hipFree(g.tileLen[i]);
-                g.tileOrder[i] = nullptr; g.tileLen[i] = nullptr;
-            }
-            if (g.tileCost) (void)hipFree(g.tileCost);
-            g.tileCost = nullptr; g.orderCap = 0;
-            for (int i = 0; i < 2; ++i) { HIPCHK(hipMalloc(&g.tileOrder[i], sizeof(uint32_t) * need)); HIPCHK(hipMalloc(&g.tileLen[i], sizeof(uint32_t) * 8)); }
-            HIPCHK(hipMalloc(&g.tileCost, sizeof(uint32_t) * need));
-            g.orderCap = need; g.orderSlots = -1;
-        }
-        if (g.orderSlots != F.slotsPerXcd || memcmp(key, g.orderKey, sizeof key) != 0) {
-            crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, g.stream>>>(g.tileOrder[g.orderCur], g.tileLen[g.orderCur], F.slotsPerXcd, F.listCap);
-            HIPCHK(hipGetLastError());
-            g.orderSlots = F.slotsPerXcd; memcpy(g.orderKey, key, sizeof key);
-        }
-        HIPCHK(hipMemsetAsync(g.tileCost, 0, sizeof(uint32_t) * (size_t)F.gridBlocks, g.stream));
-        F.order = g.tileOrder[g.orderCur]; F.listLen = g.tileLen[g.orderCur]; F.cost = g.tileCost;
-        grid = 8u * (unsigned)F.listCap;
-    }
+    if (g.feedback && !g.persistent && !g.wavefront) { rc = prepare_launch_lists(F, grid); if (rc) return rc; }
 
+    // events: [0] frame start, [1] Trace start, [2] Trace end, [3] end of PostProcess = frame end.
+    // A plain frame records only two (RayGen is fused, PostProcess off): [0] == [1], [2] == [3].
+    g.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
+    g.evPost = (flags & CRT_RENDER_POSTPROCESS) != 0;
     HIPCHK(hipEventRecord(g.ev[0], g.stream));
-    if (flags & CRT_RENDER_WRITE_RAYS) {
+    if (g.evRaygen) {
         crt_raygen_kernel<<<grid, CRT_BLOCK, 0, g.stream>>>(F, g.rays);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(g.ev[1], g.stream));
     }
-    HIPCHK(hipEventRecord(g.ev[1], g.stream));
-    if (flags & CRT_RENDER_STAMPS) {
-        const size_t need = (16 + (size_t)grid * 8) * sizeof(unsigned long long);
-        if (need > g.stampBytes) {
-            if (g.stamps) (void)hipFree(g.stamps);
-            g.stamps = nullptr; g.stampBytes = 0;
-            HIPCHK(hipMalloc(&g.stamps, need));
-            g.stampBytes = need;
-        }
-        HIPCHK(hipMemsetAsync(g.stamps, 0, need, g.stream));
-        if (g.persistent) {
-            const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
-            unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);
-            if (waves > tiles) waves = tiles;
-            g.stampWaves = waves;
-            HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
-            crt_trace_persistent_kernel<false, true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps, g.queues);
-        } else {
-            g.stampWaves = (size_t)grid;
-            crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
-        }
-    } else if (g.persistent) {
-        // persistent waves pulling tiles from per-XCD queues (crt_persistent.h)
-        const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
-        unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);
-        if (waves > tiles) waves = tiles;
-        HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
-        if (flags & CRT_RENDER_COUNTERS) {
-            HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
-            crt_trace_persistent_kernel<true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
-        } else {
-            crt_trace_persistent_kernel<false><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
-        }
-    } else if (g.wavefront) {
-        // bounce 0, compaction, bounce 1 (at most one continuing path per owned pixel)
-        const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
-        const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
-        HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), g.stream));
-        if (flags & CRT_RENDER_COUNTERS) {
-            HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
-            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
-        } else {
-            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
-        }
-    } else if (flags & CRT_RENDER_COUNTERS) {
-        HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
-        crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
-    } else {
-        crt_trace_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
-    }
-    HIPCHK(hipGetLastError());
+    rc = launch_trace(S, F, flags, grid);
+    if (rc) return rc;
     HIPCHK(hipEventRecord(g.ev[2], g.stream));
-    if (useOrder) {   // next frame's order from this frame's costs (outside the Trace event pair, inside the frame)
-        crt_order_kernel<<<8, 1024, 0, g.stream>>>(g.tileCost, g.tileOrder[g.orderCur ^ 1], g.tileLen[g.orderCur ^ 1], F.slotsPerXcd, F.listCap);
-        HIPCHK(hipGetLastError());
-        g.orderCur ^= 1;
-    }
-    if (flags & CRT_RENDER_POSTPROCESS) {
+    if (g.evPost) {
         crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, g.stream>>>(F, g.out);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(g.ev[3], g.stream));
     }
-    HIPCHK(hipEventRecord(g.ev[3], g.stream));
-    HIPCHK(hipEventRecord(g.ev[4], g.stream));
     g.pendingTiming = true; g.pendingFlags = flags;
-    if (!(flags & CRT_RENDER_ASYNC)) return crt_sync();   // the reference's clFinish (Renderer.cpp:367)
+    if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipStreamSynchronize(g.stream));   // the reference's clFinish (Renderer.cpp:367)
     return CRT_OK;
 }
 
@@ -942,7 +965,7 @@ int crt_sync(void)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     HIPCHK(hipStreamSynchronize(g.stream));
-    return collect_timing();
+    return CRT_OK;
 }
 
 int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out)
