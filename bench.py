@@ -108,12 +108,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-trace path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # CRT_BENCH_REHEARSE=1: every rank shares GPU 0 and the control plane runs over gloo -- a functional rehearsal of the
+    # N>1 path on a one-GPU box (numbers are meaningless: the ranks time-share one device)
+    rehearse = os.environ.get("CRT_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
+    red_device = "cpu" if rehearse else "cuda"
     dist = None
     if n > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     width = args.width or (1920 if n == 1 else 3840)
     height = args.height or (1080 if n == 1 else 2160)
@@ -126,7 +134,7 @@ def main():
         sc = scenes.get(args.scene)
 
     t_load = time.time()
-    s = driver.Session(width, height, device=local_rank)
+    s = driver.Session(width, height, device=device_index)
     s.load_scene(sc)
     s.set_row_bands(args.band_rows, rank, n)
     t_load = time.time() - t_load
@@ -160,7 +168,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.check(rc, "crt_render")
 
-    tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, float(np.mean(trace_ms)), "cuda")
+    tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, float(np.mean(trace_ms)), red_device)
 
     if rank == 0:
         rays_per_frame = tot["rays"]

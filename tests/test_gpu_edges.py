@@ -152,6 +152,10 @@ def test_feedback_launch_lists_never_change_pixels(nthreads):
 
         for _ in range(4):                       # identity order, then lists built from real costs (with split tiles)
             check()
+        s.render_raw(8)                          # steady state: every tile exactly once (or as four quadrants) -> counters match
+        iv, ip, pos = s.camera()
+        _, st = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
+        assert s.counters() == st
         for k in range(3):                       # moving camera: every frame runs on the previous view's costs
             s.set_camera((1.5 * k - 2.0, 9.0 + k, 12.0 - k), scenes._normalize((0.1 * k, -0.45, -1.0)))
             check()
