@@ -349,8 +349,40 @@ __global__ void crt_relayout_tris(const CrtTri* __restrict__ raw, size_t first, 
     cold[i * 2 + 1] = tail[1];
 }
 
+// ---- hot tiles: the top levels of every mesh's tree get the pair indices [0, CRT_HOT_PAIRS) ----
+// `hotSlot[leftFirst >> 1]` = hot index of the sibling pair starting at node leftFirst, or CRT_NOT_HOT. Mesh m owns the
+// slots [m * perMesh, (m + 1) * perMesh) in heap order (root pair 0; the pair under the left/right child of pair h is
+// 2h+1 / 2h+2), perMesh = the largest power of two <= CRT_HOT_PAIRS / numRoots. Every pair also keeps its ordinary record at
+// CRT_HOT_PAIRS + (leftFirst >> 1); child references point at the hot copy when there is one, so a kernel that stages
+// pairs[0 .. CRT_HOT_PAIRS) in LDS serves the most visited nodes from there, and every other kernel just sees indices.
+#define CRT_NOT_HOT 0xFFFFFFFFu
+
+__global__ void crt_assign_hot_slots(const CrtBVHNode* __restrict__ raw, uint32_t nodeCount, const uint32_t* __restrict__ roots,
+                                     uint32_t numRoots, uint32_t perMesh, uint32_t* __restrict__ hotSlot)
+{
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= numRoots || perMesh < 2) return;
+    const uint32_t root = roots[m];
+    if (root >= nodeCount) return;
+    // breadth-first over heap indices 0 .. perMesh-2; node index of the PARENT node of pair h kept in a small local queue
+    uint32_t parentOf[CRT_HOT_PAIRS];            // heap index -> node whose children form that pair (CRT_NOT_HOT = absent)
+    for (uint32_t h = 0; h + 1 < perMesh; ++h) parentOf[h] = CRT_NOT_HOT;
+    parentOf[0] = root;
+    for (uint32_t h = 0; h + 1 < perMesh; ++h) {
+        const uint32_t n = parentOf[h];
+        if (n == CRT_NOT_HOT) continue;
+        const CrtBVHNode node = raw[n];
+        if (node.triCount > 0) continue;                                   // leaf: no pair below it
+        const uint32_t l = node.leftFirst;
+        if (l <= n || (uint64_t)l + 1 >= (uint64_t)nodeCount) continue;    // invalid link: flagged by crt_relayout_nodes
+        hotSlot[l >> 1] = m * perMesh + h;
+        if (2 * h + 1 < perMesh - 1) parentOf[2 * h + 1] = l;
+        if (2 * h + 2 < perMesh - 1) parentOf[2 * h + 2] = l + 1;
+    }
+}
+
 __device__ __forceinline__ uint32_t make_ref(const CrtBVHNode& n, uint32_t self, uint32_t nodeCount, uint32_t triCap,
-                                             uint32_t* bigLeaf, int* err)
+                                             uint32_t* bigLeaf, const uint32_t* hotSlot, int* err)
 {
     if (n.triCount > 0) {
         if ((uint64_t)n.leftFirst + (uint64_t)n.triCount > (uint64_t)triCap || n.leftFirst > 0x00FFFFFFu) { atomicOr(err, 1); return CRT_LEAF_BIT | (1u << 24); }
@@ -360,11 +392,13 @@ __device__ __forceinline__ uint32_t make_ref(const CrtBVHNode& n, uint32_t self,
     }
     // children are always allocated after their parent (BVH.cpp:203-204): enforces an acyclic graph
     if (n.leftFirst <= self || (uint64_t)n.leftFirst + 1 >= (uint64_t)nodeCount) { atomicOr(err, 2); return CRT_LEAF_BIT | (1u << 24); }
-    return n.leftFirst >> 1;
+    const uint32_t hot = hotSlot[n.leftFirst >> 1];
+    return hot != CRT_NOT_HOT ? hot : (uint32_t)CRT_HOT_PAIRS + (n.leftFirst >> 1);
 }
 
 __global__ void crt_relayout_nodes(const CrtBVHNode* __restrict__ raw, uint32_t nodeCount, uint32_t triCap,
-                                   float4* __restrict__ pairs, uint32_t* __restrict__ bigLeaf, int* __restrict__ err)
+                                   float4* __restrict__ pairs, uint32_t* __restrict__ bigLeaf, const uint32_t* __restrict__ hotSlot,
+                                   int* __restrict__ err)
 {
     uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nodeCount) return;
@@ -373,24 +407,28 @@ __global__ void crt_relayout_nodes(const CrtBVHNode* __restrict__ raw, uint32_t 
     const uint32_t l = node.leftFirst;
     if (l <= n || (uint64_t)l + 1 >= (uint64_t)nodeCount) { atomicOr(err, 2); return; }
     const CrtBVHNode L = raw[l], R = raw[l + 1];
-    const uint32_t lref = make_ref(L, l, nodeCount, triCap, bigLeaf, err);
-    const uint32_t rref = make_ref(R, l + 1, nodeCount, triCap, bigLeaf, err);
-    float4* p = pairs + (size_t)(l >> 1) * 4;
-    p[0] = make_float4(L.aabbMin[0], L.aabbMin[1], L.aabbMin[2], __uint_as_float(lref));
-    p[1] = make_float4(L.aabbMax[0], L.aabbMax[1], L.aabbMax[2], 0.0f);
-    p[2] = make_float4(R.aabbMin[0], R.aabbMin[1], R.aabbMin[2], __uint_as_float(rref));
-    p[3] = make_float4(R.aabbMax[0], R.aabbMax[1], R.aabbMax[2], 0.0f);
+    const uint32_t lref = make_ref(L, l, nodeCount, triCap, bigLeaf, hotSlot, err);
+    const uint32_t rref = make_ref(R, l + 1, nodeCount, triCap, bigLeaf, hotSlot, err);
+    const float4 r0 = make_float4(L.aabbMin[0], L.aabbMin[1], L.aabbMin[2], __uint_as_float(lref));
+    const float4 r1 = make_float4(L.aabbMax[0], L.aabbMax[1], L.aabbMax[2], 0.0f);
+    const float4 r2 = make_float4(R.aabbMin[0], R.aabbMin[1], R.aabbMin[2], __uint_as_float(rref));
+    const float4 r3 = make_float4(R.aabbMax[0], R.aabbMax[1], R.aabbMax[2], 0.0f);
+    float4* p = pairs + ((size_t)CRT_HOT_PAIRS + (l >> 1)) * 4;
+    p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r3;
+    const uint32_t hot = hotSlot[l >> 1];
+    if (hot != CRT_NOT_HOT) { float4* q = pairs + (size_t)hot * 4; q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3; }
 }
 
 __global__ void crt_make_root_refs(const CrtBVHNode* __restrict__ raw, uint32_t nodeCount, uint32_t triCap,
                                    const uint32_t* __restrict__ roots, uint32_t numRoots,
-                                   uint32_t* __restrict__ rootRefs, uint32_t* __restrict__ bigLeaf, int* __restrict__ err)
+                                   uint32_t* __restrict__ rootRefs, uint32_t* __restrict__ bigLeaf, const uint32_t* __restrict__ hotSlot,
+                                   int* __restrict__ err)
 {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= numRoots) return;
     const uint32_t r = roots[k];
     if (r >= nodeCount) { rootRefs[k] = CRT_LEAF_BIT | (1u << 24); return; } // not (yet) uploaded: harmless dummy, flagged at render
-    rootRefs[k] = make_ref(raw[r], r, nodeCount, triCap, bigLeaf, err);
+    rootRefs[k] = make_ref(raw[r], r, nodeCount, triCap, bigLeaf, hotSlot, err);
 }
 
 __global__ void crt_relayout_instances(const CrtMeshInstance* __restrict__ raw, const uint32_t* __restrict__ rootRefs,
@@ -436,7 +474,7 @@ struct State {
     float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
     uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr;
     CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
-    float4* instBounds = nullptr; CrtDevInstance* devInstances = nullptr;
+    float4* instBounds = nullptr; CrtDevInstance* devInstances = nullptr; uint32_t* hotSlot = nullptr;
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
     float* rays = nullptr; float4* out = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
@@ -516,11 +554,19 @@ int rebuild_bvh_layout()
 {
     HIPCHK(hipMemsetAsync(g.err, 0, sizeof(int), g.stream));
     if (g.nodeCount) {
-        crt_relayout_nodes<<<(g.nodeCount + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.pairs, g.bigLeaf, g.err);
+        HIPCHK(hipMemsetAsync(g.hotSlot, 0xFF, ((size_t)g.nodeCount / 2 + 1) * sizeof(uint32_t), g.stream));
+        if (g.numRoots) {
+            uint32_t perMesh = 1;
+            while (perMesh * 2 * g.numRoots <= (uint32_t)CRT_HOT_PAIRS) perMesh *= 2;
+            if (perMesh * g.numRoots > (uint32_t)CRT_HOT_PAIRS) perMesh = 0;
+            crt_assign_hot_slots<<<(g.numRoots + 63) / 64, 64, 0, g.stream>>>(g.rawNodes, g.nodeCount, g.roots, g.numRoots, perMesh, g.hotSlot);
+            HIPCHK(hipGetLastError());
+        }
+        crt_relayout_nodes<<<(g.nodeCount + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.pairs, g.bigLeaf, g.hotSlot, g.err);
         HIPCHK(hipGetLastError());
     }
     if (g.numRoots) {
-        crt_make_root_refs<<<(g.numRoots + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.roots, g.numRoots, g.rootRefs, g.bigLeaf, g.err);
+        crt_make_root_refs<<<(g.numRoots + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.roots, g.numRoots, g.rootRefs, g.bigLeaf, g.hotSlot, g.err);
         HIPCHK(hipGetLastError());
     }
     int err = 0;
@@ -662,7 +708,9 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.rawNodes, g.nodeCap * sizeof(CrtBVHNode)));
     HIPCHK(hipMalloc(&g.roots, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.rawTexels, g.texelByteCap + 16));
-    HIPCHK(hipMalloc(&g.pairs, (g.nodeCap / 2 + 1) * 4 * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.pairs, (g.nodeCap / 2 + 1 + CRT_HOT_PAIRS) * 4 * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.hotSlot, (g.nodeCap / 2 + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMemset(g.pairs, 0, (size_t)CRT_HOT_PAIRS * 4 * sizeof(float4)));
     HIPCHK(hipMalloc(&g.triHot, g.triCap * 9 * sizeof(float)));
     HIPCHK(hipMalloc(&g.triCold, g.triCap * 2 * sizeof(uint4)));
     HIPCHK(hipMalloc(&g.bigLeaf, g.triCap * sizeof(uint32_t)));
@@ -704,7 +752,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.tileOrder[0], g.tileOrder[1], g.tileLen[0], g.tileLen[1], g.tileCost };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.tileOrder[0], g.tileOrder[1], g.tileLen[0], g.tileLen[1], g.tileCost };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
