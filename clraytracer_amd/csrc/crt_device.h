@@ -40,15 +40,14 @@
 #define CRT_WAVES_PER_SIMD 5
 #endif
 //  // 20 waves per CU is what the 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
-// Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126). Slots 0..CRT_LDS_SLOTS-1 of every
-// lane live in LDS (slot s of lane l at stack[s * 64 + l]: conflict-free), the rarely reached deeper slots in a
-// private (scratch) array, so a wave needs CRT_LDS_SLOTS * 256 B of LDS instead of 8 KiB and more waves fit a CU.
-#ifndef CRT_LDS_SLOTS
-#define CRT_LDS_SLOTS 16
-#endif
-#define CRT_STACK_DECL(name) __shared__ uint32_t name##_lds[CRT_LDS_SLOTS * CRT_BLOCK]; uint32_t spill[CRT_STACK_DEPTH - CRT_LDS_SLOTS]; uint32_t* stack = name##_lds + threadIdx.x
-#define CRT_STACK_WRITE(slot, v) do { const int s_ = (slot) & (CRT_STACK_DEPTH - 1); if (s_ < CRT_LDS_SLOTS) stack[s_ * CRT_BLOCK] = (v); else spill[s_ - CRT_LDS_SLOTS] = (v); } while (0)
-#define CRT_STACK_READ(slot) ((((slot) & (CRT_STACK_DEPTH - 1)) < CRT_LDS_SLOTS) ? stack[((slot) & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] : spill[((slot) & (CRT_STACK_DEPTH - 1)) - CRT_LDS_SLOTS])
+// Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126) in LDS, 32 slots x 4 B per lane = 8 KiB per
+// wave; slot s of lane l lives at stack[s * 64 + l], so a wave's ds_read/ds_write_b32 is conflict-free. Slot indices
+// wrap modulo 32 where upstream's array would overflow. 160 KiB of LDS hold the stacks of 20 waves per CU.
+// (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load. A 16-slot LDS
+// stack with the upper slots in scratch was measured too: more waves fit, but 5 -> 6 -> 8 waves/SIMD changed nothing.)
+typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
+#define CRT_STACK_WRITE(slot, v) do { stack[((slot) & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] = (v); } while (0)
+#define CRT_STACK_READ(slot, dst) do { dst = stack[((slot) & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK]; } while (0)
 #define CRT_MAX_SPLIT 96   // per XCD and frame: heaviest tiles traced as four 4x4-pixel waves instead of one 8x8 wave
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 
@@ -222,6 +221,16 @@ __device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
 // so results are bit-identical; only the interleaving between lanes differs.
 // The stack lives in LDS/scratch (CRT_STACK_*); slot indices wrap modulo 32 where upstream's array would overflow.
 // ------------------------------------------------------------------------------------------------
+// How a kernel fetches a child-pair record: straight from HBM/L2 (default), or from the LDS-staged hot tiles when
+// the pair index is below CRT_HOT_PAIRS (crt_ldstile.h).
+struct GlobalPairLoader {
+    __device__ __forceinline__ void operator()(const CrtDevScene& S, uint32_t ref, float4& lmin, float4& lmax, float4& rmin, float4& rmax) const
+    {
+        const float4* p = S.pairs + (size_t)ref * 4;
+        lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
+    }
+};
+
 template <bool COUNT>
 struct Traversal {
     v3 mo, md, inv;               // ray in the current instance's object space (direction not renormalised, hazard H6)
@@ -246,11 +255,11 @@ struct Traversal {
         active = false;
     }
     // `while (currentNodeIndex > 0 && protection++ < 250) node = stack[--currentNodeIndex]` (kernel_main.cl:131-133)
-    __device__ __forceinline__ void pop_next(uint32_t* stack, uint32_t* spill, Closest& c, LaneCounters& lc)
+    __device__ __forceinline__ void pop_next(crt_lds_u32_ptr stack, Closest& c, LaneCounters& lc)
     {
         if (sp > 0) {
             if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; finish(c); }
-            else { if (COUNT) lc.pops++; --sp; ref = CRT_STACK_READ(sp); }
+            else { if (COUNT) lc.pops++; --sp; CRT_STACK_READ(sp, ref); }
         } else finish(c);
     }
     // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root
@@ -268,10 +277,11 @@ struct Traversal {
         if (COUNT) { lc.traversals++; lc.pops++; }
     }
     // kernel_main.cl:142-157: fetch the child pair, two slab tests, near child first, far child pushed
-    __device__ __forceinline__ void inner(const CrtDevScene& S, uint32_t* stack, uint32_t* spill, Closest& c, LaneCounters& lc)
+    template <class PairLoader>
+    __device__ __forceinline__ void inner(const CrtDevScene& S, const PairLoader& loadPair, crt_lds_u32_ptr stack, Closest& c, LaneCounters& lc)
     {
-        const float4* p = S.pairs + (size_t)ref * 4;
-        const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+        float4 lmin, lmax, rmin, rmax;
+        loadPair(S, ref, lmin, lmax, rmin, rmax);
         if (COUNT) lc.innerVisits++;
         float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
         float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
@@ -280,7 +290,7 @@ struct Traversal {
             float tf = dist1; dist1 = dist2; dist2 = tf;
             uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
         }
-        if (dist1 == 1e30f) pop_next(stack, spill, c, lc);
+        if (dist1 == 1e30f) pop_next(stack, c, lc);
         else {
             ref = nearRef;
             if (dist2 != 1e30f) {
@@ -292,7 +302,7 @@ struct Traversal {
         }
     }
     // kernel_main.cl:135-140: every triangle of the leaf, then the next pop
-    __device__ __forceinline__ void leaf(const CrtDevScene& S, uint32_t* stack, uint32_t* spill, Closest& c, LaneCounters& lc)
+    __device__ __forceinline__ void leaf(const CrtDevScene& S, crt_lds_u32_ptr stack, Closest& c, LaneCounters& lc)
     {
         const uint32_t first = ref & 0x00FFFFFFu;
         uint32_t n = (ref >> 24) & 0x7Fu;
@@ -301,7 +311,7 @@ struct Traversal {
             if (COUNT) lc.triTests++;
             inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
         }
-        pop_next(stack, spill, c, lc);
+        pop_next(stack, c, lc);
     }
 };
 
@@ -338,8 +348,9 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
 //    trips for a tile whose longest ray has 361 visits; voted trips need 1.64 M at 26 lanes and 738.
 //  * small packets (quadrant waves of split tiles, tails): all three kinds run, a lane may enter, visit and test
 //    a leaf in the same trip.
-template <bool COUNT, bool ITERS = false>
-__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, uint32_t* stack, uint32_t* spill, LaneCounters& lc)
+template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader>
+__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, crt_lds_u32_ptr stack, LaneCounters& lc,
+                                               const PairLoader& loadPair = PairLoader())
 {
     Closest c;
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
@@ -373,13 +384,13 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
             if (all || runI) {
                 if (!done && T.at_inner()) {
                     if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
-                    T.inner(S, stack, spill, c, lc);
+                    T.inner(S, loadPair, stack, c, lc);
                 }
             }
             if (all || runL) {
                 if (!done && T.at_leaf()) {
                     if (ITERS) { if (first_active_lane()) lc.triTests++; }
-                    T.leaf(S, stack, spill, c, lc);
+                    T.leaf(S, stack, c, lc);
                 }
             }
         }

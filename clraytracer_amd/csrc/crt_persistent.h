@@ -48,7 +48,8 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void crt_trace_persistent_kernel(CrtD
                                                                            unsigned long long* __restrict__ counters,
                                                                            CrtQueues* __restrict__ queues)
 {
-    CRT_STACK_DECL(s_stack);
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     // DIAG builds: lane 0 keeps {service passes, lanes served, inner trips, inner lanes, leaf trips, leaf lanes, enter trips, enter lanes}
@@ -193,10 +194,10 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void crt_trace_persistent_kernel(CrtD
         const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
         if (nI > 0 && nI >= nE && nI >= nL) {
             if (DIAG) { if (lane == 0) { dg[2]++; dg[3] += nI; } }
-            if (wInner) T.inner(S, stack, spill, c, lc);
+            if (wInner) T.inner(S, GlobalPairLoader(), stack, c, lc);
         } else if (nL > 0 && nL >= nE) {
             if (DIAG) { if (lane == 0) { dg[4]++; dg[5] += nL; } }
-            if (wLeaf) T.leaf(S, stack, spill, c, lc);
+            if (wLeaf) T.leaf(S, stack, c, lc);
         } else if (nE > 0) {
             if (DIAG) { if (lane == 0) { dg[6]++; dg[7] += nE; } }
             if (wEnter) {

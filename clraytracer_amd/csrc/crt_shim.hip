@@ -47,6 +47,7 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
 }
 
 #include "crt_persistent.h"
+#include "crt_ldstile.h"
 
 // Pixel of this lane. One wave64 per workgroup owns an 8x8 pixel tile, lanes in Morton order
 // (coherent ray packets). Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
@@ -159,7 +160,8 @@ template <bool COUNT, bool STAMP = false>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                               unsigned long long* __restrict__ counters)
 {
-    CRT_STACK_DECL(s_stack);
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
     if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
         ps.energy = 1.0f;
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, spill, lc);
+            Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, lc);
             bool cont = shade_bounce(S, c, ps, bounce, F.lightY, F.lightZ);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
             if (!cont) break;
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_ker
                                                                 unsigned long long* __restrict__ counters,
                                                                 CrtBounceRay* __restrict__ queue, uint32_t* __restrict__ queueCount)
 {
-    CRT_STACK_DECL(s_stack);
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     int px, py;
     const bool active = lane_pixel(F, px, py);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_ker
         ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
         ps.d = raygen_dir(F, px, py);
         if (COUNT) { lc.rays++; lc.primary++; }
-        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, spill, lc);
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
         cont = shade_bounce(S, c, ps, 0, F.lightY, F.lightZ);
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kern
                                                                unsigned long long* __restrict__ counters,
                                                                const CrtBounceRay* __restrict__ queue, const uint32_t* __restrict__ queueCount)
 {
-    CRT_STACK_DECL(s_stack);
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     const uint32_t n = *queueCount;
     const uint32_t k = blockIdx.x * CRT_BLOCK + threadIdx.x;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kern
         const float4 partial = out[r.pixel];
         ps.result = mk3(partial.x, partial.y, partial.z);
         if (COUNT) { lc.rays++; lc.secondary++; }
-        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, spill, lc);
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
         const bool cont = shade_bounce(S, c, ps, 1, F.lightY, F.lightZ);
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[r.pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
@@ -316,14 +320,15 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    CRT_STACK_DECL(s_stack);
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;
     if (k < n) {
         v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
         v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
         lc.rays++;
-        Closest c = closest_hit<true>(S, o, d, stack, spill, lc);
+        Closest c = closest_hit<true>(S, o, d, stack, lc);
         CrtRayHit h;
         if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
         else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }
@@ -481,6 +486,7 @@ struct State {
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
     uint32_t* tileOrder[2] = { nullptr, nullptr }; uint32_t* tileLen[2] = { nullptr, nullptr }; uint32_t* tileCost = nullptr; size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 }; int feedback = 1;
+    int ldsTiles = 0; uint32_t* listNext = nullptr;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
@@ -725,8 +731,9 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
     HIPCHK(hipMalloc(&g.queues, sizeof(CrtQueues)));
     HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.listNext, 8 * sizeof(uint32_t)));
     g.numCUs = prop.multiProcessorCount;
-    { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); g.wavefront = (e && strcmp(e, "wavefront") == 0); }  // default: tile kernel (faster)
+    { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); g.wavefront = (e && strcmp(e, "wavefront") == 0); g.ldsTiles = (e && strcmp(e, "lds") == 0); }  // default: tile kernel (faster)
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
@@ -752,7 +759,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)hipStreamSynchronize(g.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.tileOrder[0], g.tileOrder[1], g.tileLen[0], g.tileLen[1], g.tileCost };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.tileOrder[0], g.tileOrder[1], g.tileLen[0], g.tileLen[1], g.tileCost };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -945,6 +952,10 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         } else {
             crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
         }
+    } else if (g.ldsTiles) {                               // resident 1024-thread workgroups, hot tiles in LDS (crt_ldstile.h)
+        HIPCHK(hipMemsetAsync(g.listNext, 0, 8 * sizeof(uint32_t), g.stream));
+        if (count) crt_trace_lds_kernel<true><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, g.stream>>>(S, F, g.out, g.counters, g.listNext);
+        else crt_trace_lds_kernel<false><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, g.stream>>>(S, F, g.out, g.counters, g.listNext);
     } else if (g.persistent) {                             // resident waves pulling tiles from per-XCD queues
         const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
         unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);

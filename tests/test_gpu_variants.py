@@ -9,10 +9,10 @@ pytestmark = pytest.mark.gpu
 FLAG_COUNT = 8
 
 
-@pytest.mark.parametrize("variant", ["persistent", "wavefront"])
+@pytest.mark.parametrize("variant", ["persistent", "wavefront", "lds"])
 def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     """The opt-in kernel structures (CRT_KERNEL=persistent: crt_persistent.h; CRT_KERNEL=wavefront: one launch per
-    bounce with ballot compaction) render the same bits and count the same work as the default megakernel."""
+    bounce with ballot compaction; CRT_KERNEL=lds: crt_ldstile.h, hot BVH tiles staged in LDS) render the same bits and count the same work as the default megakernel."""
     sc = scenes.get("tiny")
     monkeypatch.delenv("CRT_KERNEL", raising=False)
     with driver.Session(256, 144, device=0) as s:
