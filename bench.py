@@ -115,13 +115,23 @@ def main():
     torch.cuda.set_device(device_index)
     red_device = "cpu" if rehearse else "cuda"
     dist = None
-    if n > 1:
+    if n > 1 or os.environ.get("CRT_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise the RCCL control plane with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL only carries the barrier and two tiny reductions (no pixel data crosses GPUs). If it cannot come up
+            # on this node, the same control plane runs over gloo: the measurement itself is unaffected.
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                dist.barrier()
+            except Exception as e:  # pragma: no cover - depends on the node
+                sys.stderr.write(f"[bench] RCCL control plane unavailable ({e}); using gloo\n")
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend="gloo")
+                red_device = "cpu"
 
     width = args.width or (1920 if n == 1 else 3840)
     height = args.height or (1080 if n == 1 else 2160)
