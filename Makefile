@@ -15,7 +15,7 @@ HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
 
 all: $(HIP_SO) $(HOST_SO) oracle
 
-$(HIP_SO): clraytracer_amd/csrc/crt_shim.hip clraytracer_amd/csrc/crt_device.h clraytracer_amd/csrc/crt_persistent.h include/crt_api.h include/crt_types.h
+$(HIP_SO): $(wildcard clraytracer_amd/csrc/*.h) clraytracer_amd/csrc/crt_shim.hip include/crt_api.h include/crt_types.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ clraytracer_amd/csrc/crt_shim.hip
 
 $(HOST_SO): $(HOST_SRC) $(HOST_HDR) $(HIP_SO)

@@ -7,7 +7,7 @@
 // Arithmetic contract (must match oracle/crt_oracle.h "Pinned builtin semantics"): fp32, no FMA
 // contraction (-ffp-contract=off), IEEE divide/sqrt, per-ray operation order exactly upstream's.
 //
-// HBM layout (built by the relayout kernels in crt_shim.hip from the reference-layout uploads):
+// HBM layout (built by the kernels of crt_relayout.h from the reference-layout uploads):
 //   pairs   : one 64-byte, 64-byte-aligned record per sibling pair {L.min,L.ref | L.max,- |
 //             R.min,R.ref | R.max,-}; pair index = CRT_HOT_PAIRS + (leftFirst >> 1) (siblings are adjacent
 //             upstream, BVH.cpp:203-204). One inner-node visit = one aligned 64-byte fetch per lane.

@@ -1,0 +1,336 @@
+// crt_kernels.h -- the per-frame kernels of the MI355X ray-trace path (gfx950).
+//
+//   crt_trace_kernel        RayGen + Trace megakernel (kernel_main.cl:164-287), the default and dominant launch
+//   crt_primary_kernel /    wavefront form: one launch per bounce with ballot compaction (CRT_KERNEL=wavefront)
+//   crt_bounce_kernel
+//   crt_raygen_kernel       RayGen alone (kernel_main.cl:277-287), only for CRT_RENDER_WRITE_RAYS
+//   crt_postprocess_kernel  PostProcess (kernel_main.cl:342-359)
+//   crt_query_kernel        closest-hit records for explicit rays (parity tests)
+//   crt_order_kernel        feedback launch lists: per-XCD counting sort of the tiles by last frame's cost
+// Device-side traversal/shading code lives in crt_device.h; crt_persistent.h and crt_ldstile.h hold two further
+// (opt-in) kernel structures that share it.
+#pragma once
+#include "crt_device.h"
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
+__device__ __forceinline__ void flush_counters(const LaneCounters& lc, unsigned long long* g)
+{
+    // every lane of the wave must call this (inactive pixels contribute zeros)
+    uint32_t s[11] = { lc.rays, lc.primary, lc.secondary, lc.hits, lc.misses, lc.traversals, lc.pops,
+                       lc.innerVisits, lc.triTests, lc.capHits, lc.stackOverflows };
+    uint32_t mx = wave_max(lc.maxStack);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        uint32_t t = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(&g[k], (unsigned long long)t);
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&g[11], (unsigned long long)mx);
+}
+
+__device__ __forceinline__ void zero_counters(LaneCounters& lc)
+{
+    lc.rays = lc.primary = lc.secondary = lc.hits = lc.misses = 0;
+    lc.traversals = lc.pops = lc.innerVisits = lc.triTests = lc.capHits = lc.stackOverflows = lc.maxStack = 0;
+}
+
+
+// Pixel of this lane. One wave64 per workgroup owns an 8x8 pixel tile, lanes in Morton order
+// (coherent ray packets). Workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
+// b % 8), so block b takes tile row (b/8 / tilesX) * 8 + b % 8: every XCD (own 4 MiB L2) walks whole
+// tile rows left to right -- neighbouring tiles share BVH subtrees in its L2 -- while the eight XCDs
+// interleave row by row, which keeps them equally loaded when geometry is concentrated in one part
+// of the frame (a contiguous slab per XCD left most XCDs idle: ~1.2 resident waves/SIMD measured).
+// `slotOut` receives this workgroup's index into the per-tile cost array (or -1).
+__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, int* slotOut = nullptr)
+{
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    int slot = b >> 3;
+    int quadrant = -1;
+    // Feedback scheduling (crt_order_kernel): each XCD's tiles are launched heaviest-first, by the cycles the same
+    // tile cost in the previous frame, and the very heaviest are traced by four waves of one 4x4 quadrant each, so
+    // that no single wave's serial chain outlasts the rest of the frame. Nothing is cached or skipped -- only the
+    // launch order and the wave shape change. (Before: 0.45 ms with the machine full + 0.45 ms of tail.)
+    if (F.order) {
+        if ((uint32_t)slot >= F.listLen[xcd]) { if (slotOut) *slotOut = -1; return false; }
+        const uint32_t e = F.order[xcd * F.listCap + slot];
+        slot = (int)(e & 0x0FFFFFFFu);
+        if (e & 0x80000000u) quadrant = (int)((e >> 28) & 3u);
+    } else if (slot >= F.slotsPerXcd) { if (slotOut) *slotOut = -1; return false; }
+    if (slotOut) *slotOut = xcd * F.slotsPerXcd + slot;
+    const int round = slot / F.tilesX;
+    const int tx = slot - round * F.tilesX;
+    const int k = round * 8 + xcd;                     // index among the tile rows this rank owns
+    if (k >= F.ownedTileRows) return false;
+    const int bandK = k / F.tileRowsPerBand;
+    const int tileRow = (F.rank + bandK * F.nRanks) * F.tileRowsPerBand + (k - bandK * F.tileRowsPerBand);
+    const int lane = threadIdx.x & 63;
+    if (quadrant >= 0 && (lane >> 4) != quadrant) return false;   // Morton order: lanes 16q..16q+15 are one 4x4 quadrant
+    const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
+    const int ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
+    px = tx * CRT_TILE + lx;
+    py = tileRow * CRT_TILE + ly;
+    return px < F.width && py < F.height;
+}
+
+// Builds the next frame's launch lists: one workgroup per XCD, counting sort of that XCD's tiles by this frame's
+// cost, descending (1024 linear bins up to the list's maximum). The tiles that cost at least half the maximum
+// (at most CRT_MAX_SPLIT) are emitted as four quadrant entries each and come first.
+__global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
+                                                       uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap)
+{
+    __shared__ uint32_t s_bins[1024];
+    __shared__ uint32_t s_max, s_nSplit;
+    const int x = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* c = cost + (size_t)x * slotsPerXcd;
+    uint32_t* o = order + (size_t)x * listCap;
+    s_bins[tid] = 0;
+    if (tid == 0) s_max = 1;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int i = tid; i < slotsPerXcd; i += 1024) m = c[i] > m ? c[i] : m;
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const float scale = 1023.0f / (float)s_max;
+    for (int i = tid; i < slotsPerXcd; i += 1024) {
+        int bin = 1023 - (int)((float)c[i] * scale);     // heaviest -> bin 0
+        bin = bin < 0 ? 0 : (bin > 1023 ? 1023 : bin);
+        atomicAdd(&s_bins[bin], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins: one bin per thread, wave scans + a scan of the 16 wave totals
+    {
+        const uint32_t n = s_bins[tid];
+        uint32_t incl = n;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if ((tid & 63) >= off) incl += v; }
+        __shared__ uint32_t s_wave[16];
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < (tid >> 6); ++w) wbase += s_wave[w];
+        s_bins[tid] = wbase + incl - n;
+        if (tid == 511) {
+            // bins 0..511 hold cost > max/2; a frame of near-equal tiles (nothing stands out) splits nothing
+            const uint32_t heavy = wbase + incl;
+            s_nSplit = (heavy * 8u > (uint32_t)slotsPerXcd) ? 0u : (heavy < (uint32_t)CRT_MAX_SPLIT ? heavy : (uint32_t)CRT_MAX_SPLIT);
+            listLen[x] = (uint32_t)slotsPerXcd + 3u * s_nSplit;
+        }
+    }
+    __syncthreads();
+    const uint32_t nSplit = s_nSplit;
+    for (int i = tid; i < slotsPerXcd; i += 1024) {
+        int bin = 1023 - (int)((float)c[i] * scale);
+        bin = bin < 0 ? 0 : (bin > 1023 ? 1023 : bin);
+        const uint32_t pos = atomicAdd(&s_bins[bin], 1u);
+        if (pos < nSplit) { for (uint32_t q = 0; q < 4; ++q) o[4 * pos + q] = (uint32_t)i | (q << 28) | 0x80000000u; }
+        else o[3 * nSplit + pos] = (uint32_t)i;
+    }
+    __syncthreads();
+    for (int i = tid; i < slotsPerXcd; i += 1024) cost[(size_t)x * slotsPerXcd + i] = 0;    // this frame's waves add their cycles
+}
+
+__global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 8) listLen[i] = (uint32_t)slotsPerXcd;
+    if (i < 8 * slotsPerXcd) order[(i / slotsPerXcd) * listCap + (i % slotsPerXcd)] = (uint32_t)(i % slotsPerXcd);
+}
+
+// kernel Trace (kernel_main.cl:164-275) with RayGen (kernel_main.cl:277-287) fused: the ray
+// direction is computed with the same arithmetic RayGen stores, so the 24.9 MB ray buffer
+// round-trip disappears. One thread per pixel, both bounces.
+// STAMP (diagnostic build only, CRT_RENDER_STAMPS): every wave records start/end s_memrealtime (100 MHz),
+// its s_memtime cycle count and XCC/HW ids into a buffer nothing else reads.
+template <bool COUNT, bool STAMP = false>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+                                                              unsigned long long* __restrict__ counters)
+{
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    LaneCounters lc; zero_counters(lc);
+    unsigned long long t0rt = 0, t0c = 0;
+    if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
+    int px, py, costSlot = -1;
+    const unsigned long long tc0 = F.cost ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool active = lane_pixel(F, px, py, &costSlot);
+    if (active) {
+        PathState ps;
+        ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
+        ps.d = raygen_dir(F, px, py);
+        ps.result = mk3(0.0f, 0.0f, 0.0f);
+        ps.energy = 1.0f;
+        for (int bounce = 0; bounce < 2; ++bounce) {
+            if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
+            Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, lc);
+            bool cont = shade_bounce(S, c, ps, bounce, F.lightY, F.lightZ);
+            if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
+            if (!cont) break;
+        }
+        out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    if (F.cost && costSlot >= 0) {      // per-tile cost of this frame (wave-uniform value, one store)
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - tc0;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&F.cost[costSlot], dt > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)dt);   // the four waves of a split tile add up
+    }
+    if (COUNT) flush_counters(lc, counters);
+    if (STAMP) {
+        const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1rt = __builtin_amdgcn_s_memrealtime();
+        const uint32_t wOuter = wave_sum(lc.pops), wEnter = wave_sum(lc.traversals), wDescent = wave_sum(lc.innerVisits),
+                       wLeaf = wave_sum(lc.triTests), laneVisits = wave_sum(lc.rays);
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* st = counters + 16 + (size_t)blockIdx.x * 8;
+            st[4] = wOuter; st[5] = wEnter; st[6] = wDescent; st[7] = ((unsigned long long)wLeaf << 32) | laneVisits;
+            st[0] = t0rt; st[1] = t1rt; st[2] = t1c - t0c;
+            st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+        }
+    }
+}
+
+// ---- wavefront form of Trace: one launch per bounce with ballot compaction in between ----------------
+// The megakernel above runs bounce 1 inside the same wave as bounce 0, at the lane density of the pixels
+// that hit something (31 % on multi-1M) and on top of the wave's bounce-0 latency. Here bounce 0 writes the
+// pixel's partial result and appends {origin, direction, energy, pixel} of every continuing path to a queue:
+// the lanes of a wave that continue are found with one ballot, the wave reserves a contiguous queue range with
+// ONE atomic, and every lane stores its 32-byte record at base + (rank among the continuing lanes). Bounce 1
+// is then traced by dense 64-ray packets. Per-path arithmetic is unchanged: result = (partial) + (bounce-1
+// terms) in the same order as kernel_main.cl:267, so pixels are bit-identical to the megakernel.
+struct CrtBounceRay { float ox, oy, oz, energy, dx, dy, dz; uint32_t pixel; };   // 32 B
+
+template <bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+                                                                unsigned long long* __restrict__ counters,
+                                                                CrtBounceRay* __restrict__ queue, uint32_t* __restrict__ queueCount)
+{
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    LaneCounters lc; zero_counters(lc);
+    int px, py;
+    const bool active = lane_pixel(F, px, py);
+    bool cont = false;
+    PathState ps;
+    ps.o = mk3(0.f, 0.f, 0.f); ps.d = ps.o; ps.result = ps.o; ps.energy = 1.0f;
+    if (active) {
+        ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
+        ps.d = raygen_dir(F, px, py);
+        if (COUNT) { lc.rays++; lc.primary++; }
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
+        cont = shade_bounce(S, c, ps, 0, F.lightY, F.lightZ);
+        if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
+        out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    // wave-level compaction of the continuing paths
+    const unsigned long long m = __ballot(cont);
+    if (m != 0) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(queueCount, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1, 64);
+        if (cont) {
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+            CrtBounceRay r;
+            r.ox = ps.o.x; r.oy = ps.o.y; r.oz = ps.o.z; r.energy = ps.energy;
+            r.dx = ps.d.x; r.dy = ps.d.y; r.dz = ps.d.z; r.pixel = (uint32_t)py * (uint32_t)F.width + (uint32_t)px;
+            queue[base + rank] = r;
+        }
+    }
+    if (COUNT) flush_counters(lc, counters);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+                                                               unsigned long long* __restrict__ counters,
+                                                               const CrtBounceRay* __restrict__ queue, const uint32_t* __restrict__ queueCount)
+{
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    LaneCounters lc; zero_counters(lc);
+    const uint32_t n = *queueCount;
+    const uint32_t k = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    if (k < n) {
+        const CrtBounceRay r = queue[k];
+        PathState ps;
+        ps.o = mk3(r.ox, r.oy, r.oz); ps.d = mk3(r.dx, r.dy, r.dz); ps.energy = r.energy;
+        const float4 partial = out[r.pixel];
+        ps.result = mk3(partial.x, partial.y, partial.z);
+        if (COUNT) { lc.rays++; lc.secondary++; }
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
+        const bool cont = shade_bounce(S, c, ps, 1, F.lightY, F.lightZ);
+        if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
+        out[r.pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    if (COUNT) flush_counters(lc, counters);
+}
+
+// kernel RayGen as its own launch (only for CRT_RENDER_WRITE_RAYS)
+__global__ __launch_bounds__(CRT_BLOCK) void crt_raygen_kernel(CrtFrame F, float* __restrict__ rays)
+{
+    int px, py;
+    if (!lane_pixel(F, px, py)) return;
+    v3 d = raygen_dir(F, px, py);
+    float* o = rays + 3 * ((size_t)px + (size_t)py * (size_t)F.width);
+    o[0] = d.x; o[1] = d.y; o[2] = d.z;
+}
+
+// kernel PostProcess (kernel_main.cl:342-359, MathAndSTL.cl:132-169) on the float frame
+__global__ __launch_bounds__(CRT_BLOCK) void crt_postprocess_kernel(CrtFrame F, float4* __restrict__ img)
+{
+    int px, py;
+    if (!lane_pixel(F, px, py)) return;
+    const size_t idx = (size_t)py * (size_t)F.width + (size_t)px;
+    const float uvx = (float)px / (float)F.width, uvy = (float)py / (float)F.height;
+    float4 p = img[idx];
+    v3 rgb = mk3(p.x, p.y, p.z);
+    const float P = sqrtf((rgb.x * rgb.x) * 0.299f + ((rgb.y * rgb.y) * 0.587f) + ((rgb.z * rgb.z) * 0.114f));
+    const v3 Pv = mk3(P, P, P);
+    rgb = add3(Pv, scale3(sub3(rgb, Pv), 1.2f));
+    const v3 lw = mk3(0.2126f, 0.7152f, 0.0722f);
+    const float max_white_l = 0.8f;
+    const float l_old = dot3(rgb, lw);
+    const float numerator = l_old * (1.0f + (l_old / (max_white_l * max_white_l)));
+    const float l_new = numerator / (1.0f + l_old);
+    const float l_in = dot3(rgb, lw);
+    rgb = scale3(rgb, l_new / l_in);
+    const float ig = 1.0f / 1.55f;
+    rgb = mk3(powf(rgb.x, ig), powf(rgb.y, ig), powf(rgb.z, ig));
+    const float oneDivGamma = 1.0f / 1.2f;
+    rgb = mk3(powf(rgb.x, oneDivGamma), powf(rgb.y, oneDivGamma), powf(rgb.z, oneDivGamma));
+    const float vx = uvx * (1.0f - uvy), vy = uvy * (1.0f - uvx);
+    float vig = (vx * vy) * 15.0f;
+    vig = powf(vig, 0.15f);
+    rgb = scale3(rgb, vig);
+    img[idx] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+}
+
+// closest-hit query over explicit rays (hit-record parity)
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
+                                                              const float* __restrict__ dirs, int n,
+                                                              CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
+{
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    LaneCounters lc; zero_counters(lc);
+    const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;
+    if (k < n) {
+        v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
+        v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
+        lc.rays++;
+        Closest c = closest_hit<true>(S, o, d, stack, lc);
+        CrtRayHit h;
+        if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
+        else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }
+        out[k] = h;
+    }
+    flush_counters(lc, counters);
+}
+
+#include "crt_persistent.h"
+#include "crt_ldstile.h"

@@ -1,6 +1,6 @@
 // crt_persistent.h -- the production Trace kernel: persistent wave64s with per-lane pixel refill.
 //
-// Why (measured on MI355X with the one-tile-per-wave kernel in crt_shim.hip, multi-1M 1920x1080):
+// Why (measured on MI355X with the one-tile-per-wave kernel of crt_kernels.h in its first, lock-step form, multi-1M 1920x1080):
 // only 16 of 64 lanes were active per node-visit trip and the slowest wave needed 1979 trips for a
 // ray whose own path is <= 361 visits, because (a) lanes that finish their ray idle until the whole
 // 8x8 tile is done, (b) the descend-then-leaf loop nest makes every lane wait for the longest descent
