@@ -13,7 +13,19 @@ HOST_SO = clraytracer_amd/host/libcrt_host.so
 HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp)
 HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
 
-all: $(HIP_SO) $(HOST_SO) oracle
+EXAMPLE = examples/crt_headless
+
+UBENCH = tools/ubench/gather
+
+all: $(HIP_SO) $(HOST_SO) $(EXAMPLE) $(UBENCH) oracle
+
+# vector-L1 gather microbenchmark (profiles/r01_ubench_gather.txt)
+$(UBENCH): tools/ubench/gather.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+
+# the reference's EngineMain loop over the mirrored C++ API
+$(EXAMPLE): examples/headless_main.cpp $(HOST_SO)
+	$(CXX) $(CXXFLAGS) -o $@ examples/headless_main.cpp -Lclraytracer_amd/host -lcrt_host -Lclraytracer_amd/csrc -lcrt_hip -Wl,-rpath,'$$ORIGIN/../clraytracer_amd/host' -Wl,-rpath,'$$ORIGIN/../clraytracer_amd/csrc'
 
 $(HIP_SO): $(wildcard clraytracer_amd/csrc/*.h) clraytracer_amd/csrc/crt_shim.hip include/crt_api.h include/crt_types.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ clraytracer_amd/csrc/crt_shim.hip
@@ -25,7 +37,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(HIP_SO) $(HOST_SO)
+	rm -f $(HIP_SO) $(HOST_SO) $(EXAMPLE) $(UBENCH)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean
