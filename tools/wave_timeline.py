@@ -16,7 +16,9 @@ w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 with driver.Session(w, h, device=0) as s:
     s.load_scene(scenes.get(name))
-    for _ in range(3):
+    if os.environ.get("CRT_TL_RANKS"):      # this GPU plays rank 0 of N (16-row bands)
+        s.set_row_bands(16, 0, int(os.environ["CRT_TL_RANKS"]))
+    for _ in range(4):
         s.render_raw(0)
     s.render_raw(16)
     n = C.c_size_t(0)
