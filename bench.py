@@ -4,9 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One *step* = one frame through the hot path: crt_render (RayGen fused into Trace, both bounces,
-wait for completion -- the reference's Render()+clFinish, Renderer.cpp:305-367) on a scene that is
-already resident in HBM. Workload:
+One *step* = one frame through the hot path: crt_render (RayGen fused into Trace, both bounces) on a
+scene that is already resident in HBM. By default two frames are in flight (CRT_RENDER_ASYNC: frame
+k+1 is submitted while frame k runs, on its own HIP stream and output buffer, so the long-ray tail of
+one frame is hidden behind the next); all K frames are complete before the clock stops.
+`--frames-in-flight 1` gives the reference's Render()+clFinish per frame (Renderer.cpp:305-367).
+Workload:
   N == 1 : BASELINE config 4 -- `multi-1M` (8 meshes, 1,000,960 triangles, 16 instances, textures),
            1920x1080, primary + one reflection bounce.
   N  > 1 : BASELINE config 5 -- the same scene at 3840x2160, the frame cut into 16-row bands dealt
@@ -89,6 +92,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--band-rows", type=int, default=16)
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="1 = synchronous frames (Render()+clFinish), 2..4 = pipelined")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -101,6 +105,9 @@ def main():
         if world == 1 and n > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         n = world
+
+    flight = max(1, min(4, args.frames_in_flight))
+    os.environ["CRT_FRAMES_IN_FLIGHT"] = str(flight)   # read by crt_init
 
     import numpy as np
     import torch
@@ -165,20 +172,46 @@ def main():
     targs, iv, ip = s.trace_args()
     fp = C.POINTER(C.c_float)
     p_args, p_iv, p_ip = C.byref(targs), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp)
-    crt_render, crt_ms = _lib.hip().crt_render, _lib.hip().crt_last_kernel_ms
+    hip = _lib.hip()
+    crt_render = hip.crt_render
+    flags = 4 if flight > 1 else 0                # CRT_RENDER_ASYNC
+    stats = _lib.CrtFrameStats()
+
+    # N > 1: the same workload on ONE GPU (this rank renders the whole frame, untimed by the contract clock), so the
+    # line carries its own strong-scaling reference next to the N-GPU value
+    single = None
+    if n > 1 and rank == 0:
+        s.set_row_bands(args.band_rows, 0, 1)
+        for _ in range(3):
+            _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
+        _lib.check(hip.crt_sync(), "crt_sync")
+        t0 = time.perf_counter()
+        for _ in range(10):
+            rc = crt_render(p_args, p_iv, p_ip, flags)
+        _lib.check(hip.crt_sync(), "crt_sync")
+        single = (time.perf_counter() - t0) / 10
+        s.set_row_bands(args.band_rows, rank, n)
+
     for _ in range(args.warmup):
-        _lib.check(crt_render(p_args, p_iv, p_ip, 0), "crt_render")
-    trace_ms = []
+        _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
+    _lib.check(hip.crt_sync(), "crt_sync")
+    _lib.check(hip.crt_frame_time_stats(None, 1), "crt_frame_time_stats")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rc = crt_render(p_args, p_iv, p_ip, 0)   # synchronous: returns when the frame is complete (Render()+clFinish)
-        trace_ms.append(crt_ms(2))               # HIP events around the trace launch on its own stream
+        rc = crt_render(p_args, p_iv, p_ip, flags)   # flight == 1: returns when the frame is complete
+    rc2 = hip.crt_sync()                             # every frame finished
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.check(rc, "crt_render")
+    _lib.check(rc2, "crt_sync")
+    # HIP events on the launch streams, read back after the clock stopped: per-launch Trace durations (these overlap
+    # when frames are in flight) and the device-time extent first start -> last end
+    _lib.check(hip.crt_frame_time_stats(C.byref(stats), 0), "crt_frame_time_stats")
+    launch_ms = stats.sumMs[2] / max(1, stats.frames)
+    extent_ms = stats.extentMs / max(1, stats.frames)
 
-    tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, float(np.mean(trace_ms)), red_device)
+    tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, extent_ms, red_device)
 
     if rank == 0:
         rays_per_frame = tot["rays"]
@@ -186,8 +219,10 @@ def main():
         value = rays_per_frame * args.steps / elapsed_max / 1e6
         # roofline of the dominant kernel on this rank (per launch = this rank's share of one frame)
         my_bytes = algorithmic_bytes(cnt, own_rows * width)
-        my_ms = float(np.mean(trace_ms))
-        achieved = my_bytes / (my_ms * 1e-3) / 1e9
+        # GPU-level rate: bytes of one launch / device time per launch (extent of the timed region / K). With one frame
+        # in flight that is the launch duration itself; with frames in flight launches overlap, each one lasts longer
+        # (launch_duration_ms, the figure a kernel trace shows) and shares the machine with the others.
+        achieved = my_bytes / (extent_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic("crt_trace_kernel", sc.name, width, height) if n == 1 else (None, None)
         out = {
             "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
@@ -199,16 +234,23 @@ def main():
                        "scene": sc.name, "width": width, "height": height, "rays_per_frame": int(rays_per_frame),
                        "primary": int(tot["primary"]), "secondary": int(tot["secondary"]),
                        "tiling": f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
-                       "device": _lib.hip().crt_device_name().decode(), "scene_load_s": round(t_load, 2)},
-            "kernel_ms": {"crt_trace_kernel_mean": round(my_ms, 4), "crt_trace_kernel_min": round(float(np.min(trace_ms)), 4),
-                          "max_over_ranks_mean": round(kernel_ms_max, 4)},
+                       "frames_in_flight": flight,
+                       "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2)},
+            "kernel_ms": {"crt_trace_kernel_launch_mean": round(launch_ms, 4), "device_time_per_frame": round(extent_ms, 4),
+                          "frame_latency_mean": round(stats.sumMs[0] / max(1, stats.frames), 4),
+                          "device_time_per_frame_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "crt_trace_kernel<false>", "algorithmic_bytes_per_launch": int(my_bytes),
+                         "launch_duration_ms": round(launch_ms, 4), "launches_in_flight": flight,
+                         "achieved_per_launch": round(my_bytes / (launch_ms * 1e-3) / 1e9, 2),
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
                          "inner_visits_per_ray": round(cnt["innerVisits"] / max(1, cnt["rays"]), 2),
                          "tri_tests_per_ray": round(cnt["triTests"] / max(1, cnt["rays"]), 2)},
         }
+        if single is not None:
+            out["single_gpu_same_workload"] = {"value": round(rays_per_frame / single / 1e6, 2), "unit": "Mrays/s",
+                                               "ms_per_step": round(single * 1e3, 4), "note": "rank 0 alone rendering the whole frame, 10 frames, same mode"}
         if n == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib

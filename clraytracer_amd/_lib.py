@@ -23,6 +23,10 @@ class CrtTraceArgs(C.Structure):
     _fields_ = [("cameraPos", C.c_float * 3), ("time", C.c_float), ("numMeshes", C.c_uint32), ("sunAngle", C.c_float)]
 
 
+class CrtFrameStats(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("sumMs", C.c_double * 4), ("extentMs", C.c_double)]
+
+
 class CrtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "primary", "secondary", "hits", "misses", "traversals", "pops",
                                           "innerVisits", "triTests", "capHits", "stackOverflows", "maxStack")]
@@ -73,6 +77,7 @@ HIP_API = {
     "crt_output_device_ptr": (_vp, []),
     "crt_owned_rows": (C.c_int, []),
     "crt_last_kernel_ms": (C.c_float, [C.c_int]),
+    "crt_frame_time_stats": (C.c_int, [C.POINTER(CrtFrameStats), C.c_int]),
     "crt_get_counters": (C.c_int, [C.POINTER(CrtCounters)]),
     "crt_debug_read_stamps": (C.c_int, [_vp, _sz, C.POINTER(C.c_size_t)]),
     "crt_error_string": (C.c_char_p, [C.c_int]),

@@ -87,7 +87,7 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
 // cost, descending (1024 linear bins up to the list's maximum). The tiles that cost at least half the maximum
 // (at most CRT_MAX_SPLIT) are emitted as four quadrant entries each and come first.
 __global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
-                                                       uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap)
+                                                       uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap, uint32_t maxSplit)
 {
     __shared__ uint32_t s_bins[1024];
     __shared__ uint32_t s_max, s_nSplit;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ 
         if (tid == 511) {
             // bins 0..511 hold cost > max/2; a frame of near-equal tiles (nothing stands out) splits nothing
             const uint32_t heavy = wbase + incl;
-            s_nSplit = (heavy * 8u > (uint32_t)slotsPerXcd) ? 0u : (heavy < (uint32_t)CRT_MAX_SPLIT ? heavy : (uint32_t)CRT_MAX_SPLIT);
+            s_nSplit = (heavy * 8u > (uint32_t)slotsPerXcd) ? 0u : (heavy < maxSplit ? heavy : maxSplit);
             listLen[x] = (uint32_t)slotsPerXcd + 3u * s_nSplit;
         }
     }

@@ -18,12 +18,33 @@
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+#define CRT_MAX_FRAMES_IN_FLIGHT 4
+
+struct EventSet {
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool pending = false; int flags = 0; bool evRaygen = false, evPost = false;   // timing not yet read back
+    unsigned long long seq = 0;
+};
+
+struct FrameSlot {
+    hipStream_t stream = nullptr;
+    EventSet es[2];                            // two sets, so the host may queue a slot's next frame before reading the last one's timing
+    unsigned frames = 0;
+    float4* out = nullptr;
+    uint32_t* order = nullptr; uint32_t* len = nullptr; uint32_t* cost = nullptr;   // feedback launch lists
+    size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 };
+};
+
 struct State {
     bool initialized = false;
     int device = -1;
     char deviceName[256] = { 0 };
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    // Frame slots: a synchronous frame always uses slot 0; CRT_RENDER_ASYNC frames alternate between the two slots
+    // (own stream, output buffer, launch lists and events each), so the tail of one frame overlaps the next.
+    FrameSlot slot[CRT_MAX_FRAMES_IN_FLIGHT]; int nSlots = 2;
+    hipStream_t stream = nullptr;              // == slot[0].stream: uploads, queries, diagnostics
+    int cur = 0;                               // slot of the most recently submitted frame
+    unsigned asyncSeq = 0; bool othersBusy = false;   // frames possibly running on slots > 0
     int width = 0, height = 0;
     int bandRows = 16, rank = 0, nRanks = 1;
     // raw (reference-layout) device copies
@@ -34,25 +55,42 @@ struct State {
     CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
     float4* instBounds = nullptr; CrtDevInstance* devInstances = nullptr; uint32_t* hotSlot = nullptr;
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
-    float* rays = nullptr; float4* out = nullptr;
+    float* rays = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
-    uint32_t* tileOrder[2] = { nullptr, nullptr }; uint32_t* tileLen[2] = { nullptr, nullptr }; uint32_t* tileCost = nullptr; size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 }; int feedback = 1;
+    int feedback = 1; int maxSplit = CRT_MAX_SPLIT, maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED;
     int ldsTiles = 0; uint32_t* listNext = nullptr;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
     uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
     bool sceneValid = true;
-    float ms[4] = { 0, 0, 0, 0 };
-    bool timed[4] = { false, false, false, false };
-    bool pendingTiming = false; int pendingFlags = 0; bool evRaygen = false, evPost = false;
+    double msSum[4] = { 0, 0, 0, 0 }; unsigned long long framesTimed = 0;   // crt_frame_time_stats
+    float ms[4] = { 0, 0, 0, 0 }; unsigned long long msSeq = 0, frameSeq = 0;   // timing of the newest frame read back so far
+    hipEvent_t statStart = nullptr; bool statStartArmed = true, statStartValid = false; unsigned long long statStartSeq = 0; double statExtent = 0;
     CrtCounters lastCounters;
 };
 State g;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return (int)e_; } } while (0)
+#define RCCHK(x) do { int r_ = (x); if (r_ != CRT_OK) { return r_; } } while (0)
+
+// Wait for frames still running on the second slot before anything touches shared device state.
+int quiesce()
+{
+    if (g.othersBusy) {
+        for (int i = 1; i < CRT_MAX_FRAMES_IN_FLIGHT; ++i) HIPCHK(hipStreamSynchronize(g.slot[i].stream));
+        g.othersBusy = false;
+    }
+    return CRT_OK;
+}
+
+int sync_all()
+{
+    HIPCHK(hipStreamSynchronize(g.slot[0].stream));
+    return quiesce();
+}
 
 int owned_tile_rows()
 {
@@ -95,13 +133,15 @@ void fill_scene(CrtDevScene& S, uint32_t numInstances)
 int alloc_frame_buffers(int w, int h)
 {
     if (g.rays) { (void)hipFree(g.rays); g.rays = nullptr; }
-    if (g.out) { (void)hipFree(g.out); g.out = nullptr; }
+    for (FrameSlot& fs : g.slot) if (fs.out) { (void)hipFree(fs.out); fs.out = nullptr; }
     if (g.bounceQueue) { (void)hipFree(g.bounceQueue); g.bounceQueue = nullptr; }
     g.bounceCap = (size_t)w * (size_t)h;
     HIPCHK(hipMalloc(&g.bounceQueue, sizeof(CrtBounceRay) * g.bounceCap));
     HIPCHK(hipMalloc(&g.rays, sizeof(float) * 3 * (size_t)w * (size_t)h));
-    HIPCHK(hipMalloc(&g.out, sizeof(float4) * (size_t)w * (size_t)h));
-    HIPCHK(hipMemsetAsync(g.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
+    for (FrameSlot& fs : g.slot) {
+        HIPCHK(hipMalloc(&fs.out, sizeof(float4) * (size_t)w * (size_t)h));
+        HIPCHK(hipMemsetAsync(fs.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
+    }
     HIPCHK(hipStreamSynchronize(g.stream));
     g.width = w; g.height = h;
     return CRT_OK;
@@ -201,25 +241,45 @@ int rebuild_instance_bounds()
     return CRT_OK;
 }
 
-int collect_timing()
+// Event timing is read back lazily: when the slot is about to be reused (which also bounds the frames in flight to
+// one per slot), or when somebody asks. Synchronous frames are complete by then, so this never blocks them.
+int collect_set(EventSet& es)
 {
-    if (!g.pendingTiming) return CRT_OK;
-    hipEvent_t traceStart = g.evRaygen ? g.ev[1] : g.ev[0], frameEnd = g.evPost ? g.ev[3] : g.ev[2];
+    if (!es.pending) return CRT_OK;
+    hipEvent_t* ev = es.ev;
+    hipEvent_t traceStart = es.evRaygen ? ev[1] : ev[0], frameEnd = es.evPost ? ev[3] : ev[2];
     HIPCHK(hipEventSynchronize(frameEnd));
-    float t = 0;
-    HIPCHK(hipEventElapsedTime(&t, g.ev[0], frameEnd)); g.ms[0] = t;
-    g.ms[1] = 0.0f; g.ms[3] = 0.0f;
-    if (g.evRaygen) { HIPCHK(hipEventElapsedTime(&t, g.ev[0], g.ev[1])); g.ms[1] = t; }
-    HIPCHK(hipEventElapsedTime(&t, traceStart, g.ev[2])); g.ms[2] = t;
-    if (g.evPost) { HIPCHK(hipEventElapsedTime(&t, g.ev[2], g.ev[3])); g.ms[3] = t; }
-    if (g.pendingFlags & CRT_RENDER_COUNTERS) {
+    float ms[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipEventElapsedTime(&ms[0], ev[0], frameEnd));
+    if (es.evRaygen) HIPCHK(hipEventElapsedTime(&ms[1], ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms[2], traceStart, ev[2]));
+    if (es.evPost) HIPCHK(hipEventElapsedTime(&ms[3], ev[2], ev[3]));
+    for (int k = 0; k < 4; ++k) g.msSum[k] += (double)ms[k];
+    g.framesTimed++;
+    if (g.statStartValid && es.seq >= g.statStartSeq) {
+        float ext = 0;
+        HIPCHK(hipEventElapsedTime(&ext, g.statStart, frameEnd));
+        if ((double)ext > g.statExtent) g.statExtent = (double)ext;
+    }
+    if (es.seq >= g.msSeq) { memcpy(g.ms, ms, sizeof ms); g.msSeq = es.seq; }
+    if (es.flags & CRT_RENDER_COUNTERS) {
         unsigned long long c[12];
         HIPCHK(hipMemcpy(c, g.counters, sizeof c, hipMemcpyDeviceToHost));
         CrtCounters& o = g.lastCounters;
         o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
         o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
     }
-    g.pendingTiming = false;
+    es.pending = false;
+    return CRT_OK;
+}
+
+int collect_timing()
+{
+    for (FrameSlot& fs : g.slot) {
+        const int older = fs.es[0].seq <= fs.es[1].seq ? 0 : 1;
+        RCCHK(collect_set(fs.es[older]));
+        RCCHK(collect_set(fs.es[older ^ 1]));
+    }
     return CRT_OK;
 }
 
@@ -257,8 +317,13 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipGetDeviceProperties(&prop, device));
     snprintf(g.deviceName, sizeof g.deviceName, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     g.device = device;
-    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&g.ev[i]));
+    for (FrameSlot& fs : g.slot) {
+        HIPCHK(hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
+        for (EventSet& es : fs.es) for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&es.ev[i]));
+    }
+    HIPCHK(hipEventCreate(&g.statStart));
+    g.stream = g.slot[0].stream; g.cur = 0; g.asyncSeq = 0; g.othersBusy = false;
+    { const char* e = getenv("CRT_FRAMES_IN_FLIGHT"); g.nSlots = e ? atoi(e) : 2; if (g.nSlots < 1) g.nSlots = 1; if (g.nSlots > CRT_MAX_FRAMES_IN_FLIGHT) g.nSlots = CRT_MAX_FRAMES_IN_FLIGHT; }
 
     g.triCap = (size_t)CRT_MAX_TRIANGLES * 2;           // ResourceManager.cpp:158
     g.nodeCap = (size_t)CRT_MAX_TRIANGLES * 2;          // ResourceManager.cpp:159 (MAX_BVHMEMORY * 2)
@@ -287,6 +352,9 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.listNext, 8 * sizeof(uint32_t)));
     g.numCUs = prop.multiProcessorCount;
     { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); g.wavefront = (e && strcmp(e, "wavefront") == 0); g.ldsTiles = (e && strcmp(e, "lds") == 0); }  // default: tile kernel (faster)
+    { const char* e = getenv("CRT_SPLIT");               // tuning knob: cap on quadrant-split tiles per XCD (both modes)
+      if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
+      else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
@@ -310,12 +378,17 @@ int crt_init(int device, int width, int height)
 int crt_shutdown(void)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    (void)hipStreamSynchronize(g.stream);
+    (void)sync_all();
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.out, g.counters, g.err, g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.tileOrder[0], g.tileOrder[1], g.tileLen[0], g.tileLen[1], g.tileCost };
+                     g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
+                     g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext };
+    for (FrameSlot& fs : g.slot) { void* q[] = { fs.out, fs.order, fs.len, fs.cost }; for (void* p : q) if (p) (void)hipFree(p); }
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 5; ++i) if (g.ev[i]) (void)hipEventDestroy(g.ev[i]);
-    if (g.stream) (void)hipStreamDestroy(g.stream);
+    if (g.statStart) (void)hipEventDestroy(g.statStart);
+    for (FrameSlot& fs : g.slot) {
+        for (EventSet& es : fs.es) for (int i = 0; i < 4; ++i) if (es.ev[i]) (void)hipEventDestroy(es.ev[i]);
+        if (fs.stream) (void)hipStreamDestroy(fs.stream);
+    }
     g = State();
     return CRT_OK;
 }
@@ -324,7 +397,7 @@ int crt_resize(int width, int height)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (width < 16 || height < 16) return CRT_OK; // Renderer.cpp:200
-    HIPCHK(hipStreamSynchronize(g.stream));
+    RCCHK(sync_all());
     return alloc_frame_buffers(width, height);
 }
 
@@ -332,6 +405,7 @@ int crt_set_row_bands(int bandRows, int rank, int nRanks)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (bandRows < 16 || bandRows % 16 != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
+    RCCHK(sync_all());
     g.bandRows = bandRows; g.rank = rank; g.nRanks = nRanks;
     return CRT_OK;
 }
@@ -357,6 +431,7 @@ int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes)
     if (bytes == 0) return CRT_OK;
     if (!tris || byteOffset % sizeof(CrtTri) || bytes % sizeof(CrtTri)) return CRT_E_BAD_ARGUMENT;
     if (byteOffset + bytes > g.triCap * sizeof(CrtTri)) return CRT_E_OUT_OF_RANGE;
+    RCCHK(quiesce());
     HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(g.rawTris) + byteOffset, tris, bytes, hipMemcpyHostToDevice, g.stream));
     const size_t first = byteOffset / sizeof(CrtTri), count = bytes / sizeof(CrtTri);
     crt_relayout_tris<<<(unsigned)((count + 255) / 256), 256, 0, g.stream>>>(g.rawTris, first, count, g.triHot, g.triCold);
@@ -372,6 +447,7 @@ int crt_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes)
     if (bytes == 0) return CRT_OK;
     if (!nodes || byteOffset % sizeof(CrtBVHNode) || bytes % sizeof(CrtBVHNode)) return CRT_E_BAD_ARGUMENT;
     if (byteOffset + bytes > g.nodeCap * sizeof(CrtBVHNode)) return CRT_E_OUT_OF_RANGE;
+    RCCHK(quiesce());
     HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(g.rawNodes) + byteOffset, nodes, bytes, hipMemcpyHostToDevice, g.stream));
     const uint32_t high = (uint32_t)((byteOffset + bytes) / sizeof(CrtBVHNode));
     if (high > g.nodeCount) g.nodeCount = high;
@@ -384,6 +460,7 @@ int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count)
     if (count == 0) return CRT_OK;
     if (!roots) return CRT_E_BAD_ARGUMENT;
     if (firstMesh + count > CRT_MAX_MESHES) return CRT_E_OUT_OF_RANGE;
+    RCCHK(quiesce());
     HIPCHK(hipMemcpyAsync(g.roots + firstMesh, roots, count * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
     memcpy(g.hRoots + firstMesh, roots, count * sizeof(uint32_t));
     if (firstMesh + count > g.numRoots) g.numRoots = (uint32_t)(firstMesh + count);
@@ -396,6 +473,7 @@ int crt_upload_materials(const void* materials, size_t first, size_t count)
     if (count == 0) return CRT_OK;
     if (!materials) return CRT_E_BAD_ARGUMENT;
     if (first + count > CRT_MAX_MATERIALS) return CRT_E_OUT_OF_RANGE;
+    RCCHK(quiesce());
     HIPCHK(hipMemcpyAsync(g.materials + first, materials, count * sizeof(CrtMaterial), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return CRT_OK;
@@ -407,6 +485,7 @@ int crt_upload_texture_table(const void* textures, size_t count)
     if (count == 0) return CRT_OK;
     if (!textures) return CRT_E_BAD_ARGUMENT;
     if (count > CRT_MAX_TEXTURES) return CRT_E_OUT_OF_RANGE;
+    RCCHK(quiesce());
     HIPCHK(hipMemcpyAsync(g.textures, textures, count * sizeof(CrtTexture), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     return CRT_OK;
@@ -418,6 +497,7 @@ int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes)
     if (bytes == 0) return CRT_OK;
     if (!rgb8) return CRT_E_BAD_ARGUMENT;
     if (byteOffset + bytes > g.texelByteCap) return CRT_E_OUT_OF_RANGE;
+    RCCHK(quiesce());
     HIPCHK(hipMemcpyAsync(g.rawTexels + byteOffset, rgb8, bytes, hipMemcpyHostToDevice, g.stream));
     if (byteOffset + bytes > g.texelBytesHigh) g.texelBytesHigh = byteOffset + bytes;
     const size_t firstTexel = byteOffset / 3;
@@ -439,6 +519,7 @@ int crt_upload_instances(const void* instances, size_t first, size_t count)
     if (first + count > CRT_MAX_INSTANCES) return CRT_E_OUT_OF_RANGE;
     const CrtMeshInstance* in = static_cast<const CrtMeshInstance*>(instances);
     for (size_t i = 0; i < count; ++i) if (in[i].meshIndex >= CRT_MAX_MESHES) return CRT_E_BAD_ARGUMENT;
+    RCCHK(quiesce());
     HIPCHK(hipMemcpyAsync(g.instances + first, instances, count * sizeof(CrtMeshInstance), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     memcpy(g.hInstances + first, instances, count * sizeof(CrtMeshInstance));
@@ -450,39 +531,39 @@ int crt_upload_instances(const void* instances, size_t first, size_t count)
 // change of geometry resets to the identity order. Every frame starts by turning the previous frame's per-tile
 // costs into this frame's lists (and zeroing the costs), so the sort is inside the frame but outside the Trace
 // event pair.
-static int prepare_launch_lists(CrtFrame& F, unsigned& grid)
+static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool pipelined)
 {
     const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
     F.listCap = F.slotsPerXcd + 3 * CRT_MAX_SPLIT;
     const size_t need = (size_t)8 * (size_t)F.listCap;
-    if (need > g.orderCap) {
-        if (g.tileOrder[0]) (void)hipFree(g.tileOrder[0]);
-        if (g.tileLen[0]) (void)hipFree(g.tileLen[0]);
-        if (g.tileCost) (void)hipFree(g.tileCost);
-        g.tileOrder[0] = nullptr; g.tileLen[0] = nullptr; g.tileCost = nullptr; g.orderCap = 0;
-        HIPCHK(hipMalloc(&g.tileOrder[0], sizeof(uint32_t) * need));
-        HIPCHK(hipMalloc(&g.tileLen[0], sizeof(uint32_t) * 8));
-        HIPCHK(hipMalloc(&g.tileCost, sizeof(uint32_t) * need));
-        g.orderCap = need; g.orderSlots = -1;
+    if (need > fs.orderCap) {
+        if (fs.order) (void)hipFree(fs.order);
+        if (fs.len) (void)hipFree(fs.len);
+        if (fs.cost) (void)hipFree(fs.cost);
+        fs.order = nullptr; fs.len = nullptr; fs.cost = nullptr; fs.orderCap = 0;
+        HIPCHK(hipMalloc(&fs.order, sizeof(uint32_t) * need));
+        HIPCHK(hipMalloc(&fs.len, sizeof(uint32_t) * 8));
+        HIPCHK(hipMalloc(&fs.cost, sizeof(uint32_t) * need));
+        fs.orderCap = need; fs.orderSlots = -1;
     }
-    if (g.orderSlots != F.slotsPerXcd || memcmp(key, g.orderKey, sizeof key) != 0) {
-        HIPCHK(hipMemsetAsync(g.tileCost, 0, sizeof(uint32_t) * need, g.stream));
-        crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, g.stream>>>(g.tileOrder[0], g.tileLen[0], F.slotsPerXcd, F.listCap);
-        g.orderSlots = F.slotsPerXcd; memcpy(g.orderKey, key, sizeof key);
+    if (fs.orderSlots != F.slotsPerXcd || memcmp(key, fs.orderKey, sizeof key) != 0) {
+        HIPCHK(hipMemsetAsync(fs.cost, 0, sizeof(uint32_t) * need, fs.stream));
+        crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, fs.stream>>>(fs.order, fs.len, F.slotsPerXcd, F.listCap);
+        fs.orderSlots = F.slotsPerXcd; memcpy(fs.orderKey, key, sizeof key);
     } else {
-        crt_order_kernel<<<8, 1024, 0, g.stream>>>(g.tileCost, g.tileOrder[0], g.tileLen[0], F.slotsPerXcd, F.listCap);
+        crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit));
     }
     HIPCHK(hipGetLastError());
-    F.order = g.tileOrder[0]; F.listLen = g.tileLen[0]; F.cost = g.tileCost;
+    F.order = fs.order; F.listLen = fs.len; F.cost = fs.cost;
     grid = 8u * (unsigned)F.listCap;
     return CRT_OK;
 }
 
 // The Trace launch(es) of one frame, by kernel structure (default: megakernel with feedback launch lists).
-static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid)
+static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid, FrameSlot& fs)
 {
     const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
-    if (count) HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
+    if (count) HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), fs.stream));
     if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
         unsigned waves = grid;
         if (g.persistent) {
@@ -498,39 +579,39 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             g.stampBytes = need;
         }
         g.stampWaves = waves;
-        HIPCHK(hipMemsetAsync(g.stamps, 0, need, g.stream));
+        HIPCHK(hipMemsetAsync(g.stamps, 0, need, fs.stream));
         if (g.persistent) {
-            HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
-            crt_trace_persistent_kernel<false, true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps, g.queues);
+            HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), fs.stream));
+            crt_trace_persistent_kernel<false, true><<<waves, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.stamps, g.queues);
         } else {
-            crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.stamps);
+            crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.stamps);
         }
     } else if (g.ldsTiles) {                               // resident 1024-thread workgroups, hot tiles in LDS (crt_ldstile.h)
-        HIPCHK(hipMemsetAsync(g.listNext, 0, 8 * sizeof(uint32_t), g.stream));
-        if (count) crt_trace_lds_kernel<true><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, g.stream>>>(S, F, g.out, g.counters, g.listNext);
-        else crt_trace_lds_kernel<false><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, g.stream>>>(S, F, g.out, g.counters, g.listNext);
+        HIPCHK(hipMemsetAsync(g.listNext, 0, 8 * sizeof(uint32_t), fs.stream));
+        if (count) crt_trace_lds_kernel<true><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, fs.stream>>>(S, F, fs.out, g.counters, g.listNext);
+        else crt_trace_lds_kernel<false><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, fs.stream>>>(S, F, fs.out, g.counters, g.listNext);
     } else if (g.persistent) {                             // resident waves pulling tiles from per-XCD queues
         const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
         unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);
         if (waves > tiles) waves = tiles;
-        HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), g.stream));
-        if (count) crt_trace_persistent_kernel<true><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
-        else crt_trace_persistent_kernel<false><<<waves, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.queues);
+        HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), fs.stream));
+        if (count) crt_trace_persistent_kernel<true><<<waves, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.queues);
+        else crt_trace_persistent_kernel<false><<<waves, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.queues);
     } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
         const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
         const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
-        HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), g.stream));
+        HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), fs.stream));
         if (count) {
-            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
         } else {
-            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
         }
     } else if (count) {
-        crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
+        crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
     } else {
-        crt_trace_kernel<false><<<grid, CRT_BLOCK, 0, g.stream>>>(S, F, g.out, g.counters);
+        crt_trace_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
     }
     HIPCHK(hipGetLastError());
     return CRT_OK;
@@ -542,42 +623,61 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     if (!args || !invView || !invProj) return CRT_E_BAD_ARGUMENT;
     if (args->numMeshes > CRT_MAX_INSTANCES) return CRT_E_OUT_OF_RANGE;
     if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
-    int rc = collect_timing();
-    if (rc) return rc;
+    int rc = CRT_OK;
     CrtFrame F; fill_frame(F, args, invView, invProj);
     CrtDevScene S; fill_scene(S, args->numMeshes);
     if (F.gridBlocks == 0) return CRT_OK;
     unsigned grid = (unsigned)F.gridBlocks;
-    if (g.feedback && !g.persistent && !g.wavefront) { rc = prepare_launch_lists(F, grid); if (rc) return rc; }
+
+    // Slot choice: plain ASYNC frames of the default kernel alternate between the two slots so consecutive frames
+    // overlap (each slot has its own stream, output buffer and launch lists). Everything else -- synchronous frames,
+    // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
+    const bool variant = g.persistent || g.wavefront || g.ldsTiles;
+    const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
+                        && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
+    int slot = 0;
+    if (pipelined) slot = (int)(g.asyncSeq++ % (unsigned)g.nSlots);
+    else { rc = quiesce(); if (rc) return rc; }
+    FrameSlot& fs = g.slot[slot];
+    EventSet& es = fs.es[fs.frames & 1u];
+    rc = collect_set(es);                    // waits for the frame two back on this slot: at most two queued per slot
+    if (rc) return rc;
+    if (flags & CRT_RENDER_COUNTERS) { rc = collect_timing(); if (rc) return rc; }
+    if (slot != 0) g.othersBusy = true;
+    if (g.feedback && !g.persistent && !g.wavefront) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
 
     // events: [0] frame start, [1] Trace start, [2] Trace end, [3] end of PostProcess = frame end.
     // A plain frame records only two (RayGen is fused, PostProcess off): [0] == [1], [2] == [3].
-    g.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
-    g.evPost = (flags & CRT_RENDER_POSTPROCESS) != 0;
-    HIPCHK(hipEventRecord(g.ev[0], g.stream));
-    if (g.evRaygen) {
-        crt_raygen_kernel<<<grid, CRT_BLOCK, 0, g.stream>>>(F, g.rays);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(g.ev[1], g.stream));
+    if (g.statStartArmed) {                  // first frame since the statistics were reset: start of the extent
+        HIPCHK(hipEventRecord(g.statStart, fs.stream));
+        g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0;
     }
-    rc = launch_trace(S, F, flags, grid);
+    es.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
+    es.evPost = (flags & CRT_RENDER_POSTPROCESS) != 0;
+    HIPCHK(hipEventRecord(es.ev[0], fs.stream));
+    if (es.evRaygen) {
+        crt_raygen_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, g.rays);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(es.ev[1], fs.stream));
+    }
+    rc = launch_trace(S, F, flags, grid, fs);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(g.ev[2], g.stream));
-    if (g.evPost) {
-        crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, g.stream>>>(F, g.out);
+    HIPCHK(hipEventRecord(es.ev[2], fs.stream));
+    if (es.evPost) {
+        crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(g.ev[3], g.stream));
+        HIPCHK(hipEventRecord(es.ev[3], fs.stream));
     }
-    g.pendingTiming = true; g.pendingFlags = flags;
-    if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipStreamSynchronize(g.stream));   // the reference's clFinish (Renderer.cpp:367)
+    g.cur = slot;
+    es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
+    if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipStreamSynchronize(fs.stream));   // the reference's clFinish (Renderer.cpp:367)
     return CRT_OK;
 }
 
 int crt_sync(void)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return CRT_OK;
+    return sync_all();
 }
 
 int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out)
@@ -588,6 +688,7 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
     int rc = collect_timing();
     if (rc) return rc;
+    RCCHK(quiesce());
     const size_t rayBytes = sizeof(float) * 3 * (size_t)n, need = rayBytes * 2 + sizeof(CrtRayHit) * (size_t)n;
     if (need > g.queryBytes) {
         if (g.queryBuf) (void)hipFree(g.queryBuf);
@@ -618,8 +719,8 @@ int crt_read_output(float* dst, size_t floats)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || floats != (size_t)g.width * (size_t)g.height * 4) return CRT_E_BAD_ARGUMENT;
-    HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(dst, g.out, floats * sizeof(float), hipMemcpyDeviceToHost));
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, g.slot[g.cur].out, floats * sizeof(float), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
@@ -627,8 +728,8 @@ int crt_read_output_rows(float* dst, int row0, int rows)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || row0 < 0 || rows < 0 || row0 + rows > g.height) return CRT_E_BAD_ARGUMENT;
-    HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(dst, g.out + (size_t)row0 * (size_t)g.width, (size_t)rows * (size_t)g.width * sizeof(float4), hipMemcpyDeviceToHost));
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, g.slot[g.cur].out + (size_t)row0 * (size_t)g.width, (size_t)rows * (size_t)g.width * sizeof(float4), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
@@ -636,18 +737,34 @@ int crt_read_rays(float* dst, size_t floats)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || floats != (size_t)g.width * (size_t)g.height * 3) return CRT_E_BAD_ARGUMENT;
-    HIPCHK(hipStreamSynchronize(g.stream));
+    RCCHK(sync_all());
     HIPCHK(hipMemcpy(dst, g.rays, floats * sizeof(float), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
-void* crt_output_device_ptr(void) { return g.initialized ? (void*)g.out : nullptr; }
+void* crt_output_device_ptr(void) { return g.initialized ? (void*)g.slot[g.cur].out : nullptr; }
 
 float crt_last_kernel_ms(int which)
 {
     if (!g.initialized || which < 0 || which > 3) return -1.0f;
     if (collect_timing() != CRT_OK) return -1.0f;
     return g.ms[which];
+}
+
+int crt_frame_time_stats(CrtFrameStats* out, int reset)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    RCCHK(collect_timing());
+    if (out) {
+        out->frames = g.framesTimed;
+        for (int k = 0; k < 4; ++k) out->sumMs[k] = g.msSum[k];
+        out->extentMs = g.statExtent;
+    }
+    if (reset) {
+        for (int k = 0; k < 4; ++k) g.msSum[k] = 0.0;
+        g.framesTimed = 0; g.statExtent = 0; g.statStartArmed = true; g.statStartValid = false;
+    }
+    return CRT_OK;
 }
 
 int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
@@ -657,7 +774,7 @@ int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
     *numWaves = g.stampWaves;
     if (!dst || !g.stamps) return CRT_OK;
     const size_t n = maxWaves < g.stampWaves ? maxWaves : g.stampWaves;
-    HIPCHK(hipStreamSynchronize(g.stream));
+    RCCHK(sync_all());
     HIPCHK(hipMemcpy(dst, g.stamps + 16, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRT_OK;
 }

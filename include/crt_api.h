@@ -39,7 +39,7 @@ enum {
 enum {
     CRT_RENDER_POSTPROCESS = 1,   /* also run PostProcess (kernel_main.cl:342-359) on the output */
     CRT_RENDER_WRITE_RAYS  = 2,   /* materialise the RayGen buffer (kernel_main.cl:277-287) in HBM */
-    CRT_RENDER_ASYNC       = 4,   /* do not wait for completion (the reference always clFinish()es) */
+    CRT_RENDER_ASYNC       = 4,   /* do not wait for completion (the reference always clFinish()es); see crt_render */
     CRT_RENDER_COUNTERS    = 8,   /* instrumented launch that fills the work counters (slower) */
     CRT_RENDER_STAMPS      = 16   /* diagnostic launch: per-wave start/end clock stamps (crt_debug_read_stamps) */
 };
@@ -83,9 +83,15 @@ int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes);
 int crt_upload_instances(const void* instances, size_t first, size_t count);
 
 /* Renderer.cpp:337-367: RayGen + Trace (+ PostProcess) for one frame, then (unless ASYNC) wait.
- * invView / invProj are the camera's inverse matrices, row-major (hazard H10: taken as inputs). */
+ * invView / invProj are the camera's inverse matrices, row-major (hazard H10: taken as inputs).
+ * Frames in flight (no reference counterpart): consecutive CRT_RENDER_ASYNC frames alternate between two frame
+ * slots (CRT_FRAMES_IN_FLIGHT=1..4 in the environment, default 2), each with its own HIP stream, output buffer and
+ * launch lists, so two frames run concurrently and the long-ray tail of one is hidden behind the other; the call
+ * blocks only to keep at most two frames queued per slot. Uploads, resize, queries and reads wait for every frame
+ * in flight first, so scene edits between frames stay ordered. crt_read_output* and crt_output_device_ptr refer
+ * to the most recently submitted frame. */
 int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags);
-int crt_sync(void);
+int crt_sync(void);                                           /* wait for every frame in flight */
 
 /* Closest-hit query for arbitrary world-space rays (host pointers, n rays) against the first
  * `numInstances` instances: the instance loop + IntersectBVH of kernel_main.cl:198-217 exposed for
@@ -102,6 +108,16 @@ int crt_owned_rows(void);                                     /* rows this rank 
 /* Timing of the last crt_render measured with HIP events on the launch stream.
  * which: 0 = whole frame, 1 = RayGen (only with WRITE_RAYS), 2 = Trace, 3 = PostProcess. */
 float crt_last_kernel_ms(int which);
+/* Event timing accumulated over every frame since the last reset. Read back lazily per frame slot, so this does
+ * not serialise ASYNC frames the way asking crt_last_kernel_ms after each frame would. With frames in flight the
+ * per-frame durations overlap: sumMs[2] / frames is the mean duration of one Trace launch (what a kernel trace
+ * shows), extentMs / frames the device time the frames took per frame. */
+typedef struct CrtFrameStats {
+    uint64_t frames;
+    double sumMs[4];      /* same four intervals as crt_last_kernel_ms */
+    double extentMs;      /* start of the first frame -> end of the last one to finish */
+} CrtFrameStats;
+int crt_frame_time_stats(CrtFrameStats* out, int reset);
 int crt_get_counters(CrtCounters* out);
 /* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 8 x uint64 {start, end (s_memrealtime, 100 MHz),
  * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer / enter-instance / descent loops,

@@ -168,3 +168,49 @@ def test_feedback_launch_lists_never_change_pixels(nthreads):
         full = s.read_output()
         own = np.array([_lib.hip().crt_row_owner(y, 16, 2) == 1 for y in range(s.height)])
         assert np.array_equal(bits(part[own]), bits(full[own]))
+
+
+def test_frames_in_flight_match_synchronous_frames(nthreads):
+    """CRT_RENDER_ASYNC frames alternate between frame slots (own stream / output buffer / launch lists). Pixels must
+    be those of a synchronous frame; uploads between ASYNC frames must be ordered after the frames already queued
+    and before the next one; the accumulated event timing covers every frame."""
+    sc = scenes.get("tiny")
+    ASYNC = 4
+    with driver.Session(200, 120, device=0) as s:
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        hip = _lib.hip()
+
+        def oracle_frame():
+            iv, ip, pos = s.camera()
+            return orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)[0]
+
+        ref0 = oracle_frame()
+        assert hip.crt_frame_time_stats(None, 1) == 0
+        for _ in range(7):
+            s.render_raw(ASYNC)
+        assert np.array_equal(bits(s.read_output()), bits(ref0))          # read waits for the frames in flight
+        st = _lib.CrtFrameStats()
+        assert hip.crt_frame_time_stats(C.byref(st), 1) == 0
+        assert st.frames == 7 and st.sumMs[2] > 0 and 0 < st.extentMs <= st.sumMs[0] * 1.001 + 1e-3
+        # every slot's buffer holds the same frame: 8 more frames end on the other slot parity
+        s.render_raw(ASYNC)
+        assert np.array_equal(bits(s.read_output()), bits(ref0))
+        # scene edit between ASYNC frames: the upload waits for queued frames, the next frame sees it
+        m = sc.instances[1].matrix.copy(); m[3, :3] += np.array([0.8, 0.4, -0.3], np.float32)
+        p, keep = _lib.fptr(m)
+        s.render_raw(ASYNC); s.render_raw(ASYNC)
+        s.h.crth_set_mesh_matrix(1, p)
+        s.render(postprocess=False)                                       # mirrored Renderer: uploads the dirty range, then a synchronous frame
+        moved = s.output().copy()
+        s.render_raw(ASYNC); s.render_raw(ASYNC); s.render_raw(ASYNC)
+        orc2 = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        ref1 = orc2.trace(orc2.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)[0]
+        assert not np.array_equal(bits(ref0), bits(ref1))
+        assert np.array_equal(bits(moved), bits(ref1)) and np.array_equal(bits(s.read_output()), bits(ref1))
+        # instrumented and synchronous frames still work in between, with exact counters
+        s.render_raw(ASYNC); s.render_raw(8)
+        _, stc = orc2.trace(orc2.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
+        assert s.counters() == stc
+        assert np.array_equal(bits(s.read_output()), bits(ref1))
