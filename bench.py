@@ -47,7 +47,7 @@ def algorithmic_bytes(c, pixels):
     return per_ray + per_hit + per_miss + per_pixel
 
 
-COUNTER_KEYS = ["rays", "primary", "secondary", "hits", "misses", "traversals", "pops", "innerVisits", "triTests"]
+COUNTER_KEYS = ["rays", "primary", "secondary", "hits", "misses", "traversals", "pops", "innerVisits", "triTests", "shadowRays"]
 
 
 def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device):
@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--band-rows", type=int, default=16)
     ap.add_argument("--frames-in-flight", type=int, default=2, help="1 = synchronous frames (Render()+clFinish), 2..4 = pipelined")
+    ap.add_argument("--shadows", action="store_true", help="extension: one any-hit shadow ray per lit first hit (CRT_RENDER_SHADOWS); not the reference's semantics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -157,7 +158,7 @@ def main():
     t_load = time.time() - t_load
 
     # instrumented launch (untimed): rays and work counters of this rank's share of the frame
-    s.render_raw(8)
+    s.render_raw(8 | (32 if args.shadows else 0))
     cnt = s.counters()
     own_rows = s.owned_rows()
 
@@ -174,7 +175,7 @@ def main():
     p_args, p_iv, p_ip = C.byref(targs), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp)
     hip = _lib.hip()
     crt_render = hip.crt_render
-    flags = 4 if flight > 1 else 0                # CRT_RENDER_ASYNC
+    flags = (4 if flight > 1 else 0) | (32 if args.shadows else 0)   # CRT_RENDER_ASYNC, CRT_RENDER_SHADOWS
     stats = _lib.CrtFrameStats()
 
     # N > 1: the same workload on ONE GPU (this rank renders the whole frame, untimed by the contract clock), so the
@@ -223,16 +224,16 @@ def main():
         # in flight that is the launch duration itself; with frames in flight launches overlap, each one lasts longer
         # (launch_duration_ms, the figure a kernel trace shows) and shares the machine with the others.
         achieved = my_bytes / (extent_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("crt_trace_kernel", sc.name, width, height) if n == 1 else (None, None)
+        traffic, traffic_src = pmc_traffic("crt_trace_kernel", sc.name, width, height) if (n == 1 and not args.shadows) else (None, None)
         out = {
             "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{sc.name}: {sc.num_tris} triangles, {len(sc.meshes)} meshes, {len(sc.instances)} instances, "
-                                   f"{width}x{height}, primary + 1 reflection bounce, RayGen fused",
+                                   f"{width}x{height}, primary + 1 reflection bounce" + (" + 1 shadow ray per lit first hit (extension)" if args.shadows else "") + ", RayGen fused",
                        "scene": sc.name, "width": width, "height": height, "rays_per_frame": int(rays_per_frame),
-                       "primary": int(tot["primary"]), "secondary": int(tot["secondary"]),
+                       "primary": int(tot["primary"]), "secondary": int(tot["secondary"]), "shadow": int(tot["shadowRays"]),
                        "tiling": f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
                        "frames_in_flight": flight,
                        "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2)},
@@ -241,7 +242,7 @@ def main():
                           "device_time_per_frame_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "crt_trace_kernel<false>", "algorithmic_bytes_per_launch": int(my_bytes),
+                         "kernel": "crt_trace_kernel<false, false, true>" if args.shadows else "crt_trace_kernel<false, false, false>", "algorithmic_bytes_per_launch": int(my_bytes),
                          "launch_duration_ms": round(launch_ms, 4), "launches_in_flight": flight,
                          "achieved_per_launch": round(my_bytes / (launch_ms * 1e-3) / 1e9, 2),
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
@@ -259,7 +260,7 @@ def main():
             iv, ip, pos = s.camera()
             rays = orc.raygen(width, height, iv, ip)
             t0 = time.perf_counter()
-            _, st = orc.trace(rays, pos, sc.sun_angle)
+            _, st = orc.trace(rays, pos, sc.sun_angle, shadows=args.shadows)
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                                    "sample": f"one full {width}x{height} frame of the same scene ({st['rays']} rays, {dt:.2f} s wall)",

@@ -29,7 +29,8 @@ class CrtFrameStats(C.Structure):
 
 class CrtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "primary", "secondary", "hits", "misses", "traversals", "pops",
-                                          "innerVisits", "triTests", "capHits", "stackOverflows", "maxStack")]
+                                          "innerVisits", "triTests", "capHits", "stackOverflows", "maxStack",
+                                          "shadowRays", "shadowHits")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

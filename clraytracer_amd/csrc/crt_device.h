@@ -125,6 +125,7 @@ struct Triout { float t, u, v; uint32_t tri; };
 struct LaneCounters {
     uint32_t rays, primary, secondary, hits, misses;
     uint32_t traversals, pops, innerVisits, triTests, capHits, stackOverflows, maxStack;
+    uint32_t shadowRays, shadowHits;      // CRT_RENDER_SHADOWS only
 };
 
 // kernel_main.cl:108-117
@@ -302,7 +303,9 @@ struct Traversal {
             }
         }
     }
-    // kernel_main.cl:135-140: every triangle of the leaf, then the next pop
+    // kernel_main.cl:135-140: every triangle of the leaf, then the next pop.
+    // ANYHIT (shadow rays): the traversal ends at the first triangle that passes.
+    template <bool ANYHIT = false>
     __device__ __forceinline__ void leaf(const CrtDevScene& S, crt_lds_u32_ptr stack, Closest& c, LaneCounters& lc)
     {
         const uint32_t first = ref & 0x00FFFFFFu;
@@ -311,15 +314,17 @@ struct Traversal {
         for (uint32_t i = first, end = first + n; i < end; ++i) {
             if (COUNT) lc.triTests++;
             inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
+            if (ANYHIT) { if (inters) break; }
         }
-        pop_next(stack, c, lc);
+        if (ANYHIT && inters) finish(c);
+        else pop_next(stack, c, lc);
     }
 };
 
 // Conservative candidate mask for instances [base, base + cnt): bit k is cleared only when the ray provably misses
 // instance base+k's bounding sphere (any NaN -> candidate). A culled instance costs upstream exactly one pop and one
 // inner visit and changes nothing, which is what the counters record for it. Wave-uniform loop, scalar loads.
-template <bool COUNT>
+template <bool COUNT, bool DEFER_COUNT = false>
 __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& S, v3 o, v3 d, uint32_t base, uint32_t cnt, LaneCounters& lc)
 {
     const float dd = dot3(d, d);
@@ -332,7 +337,7 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
         const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
         if (!cull) cand |= 1ull << k;
     }
-    if (COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(cand); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
+    if (COUNT && !DEFER_COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(cand); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
     return cand;
 }
 
@@ -349,7 +354,10 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
 //    trips for a tile whose longest ray has 361 visits; voted trips need 1.64 M at 26 lanes and 738.
 //  * small packets (quadrant waves of split tiles, tails): all three kinds run, a lane may enter, visit and test
 //    a leaf in the same trip.
-template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader>
+// ANYHIT (shadow rays, CRT_RENDER_SHADOWS): a lane stops at the first triangle that passes -- inside the leaf, and
+// for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
+// first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
+template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader, bool ANYHIT = false>
 __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, crt_lds_u32_ptr stack, LaneCounters& lc,
                                                const PairLoader& loadPair = PairLoader())
 {
@@ -360,8 +368,11 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
 
     for (uint32_t base = 0; base < S.numInstances; base += 64) {
         const uint32_t cnt = (S.numInstances - base) < 64u ? (S.numInstances - base) : 64u;
-        unsigned long long cand = candidate_mask<COUNT>(S, o, d, base, cnt, lc);
-        bool done = false;
+        unsigned long long cand = candidate_mask<COUNT, ANYHIT>(S, o, d, base, cnt, lc);
+        // ANYHIT + COUNT: a culled instance is only "visited" (one pop, one inner visit upstream) if the ray gets that
+        // far, so culled instances are counted when a later candidate is entered or the chunk ends without a hit
+        unsigned long long culledLeft = (COUNT && ANYHIT) ? (~cand & (cnt == 64u ? ~0ull : ((1ull << cnt) - 1ull))) : 0ull;
+        bool done = ANYHIT && c.anyHit;
         for (;;) {
             const bool wEnter = !done && !T.active;
             const bool wInner = !done && T.at_inner();
@@ -373,11 +384,19 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
             const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
             if (all || (!runI && !runL)) {
                 if (wEnter) {
-                    if (cand == 0) done = true;                    // this lane is finished with the chunk
-                    else {
+                    if (ANYHIT && c.anyHit) done = true;           // occluded: later instances are never visited
+                    else if (cand == 0) {                          // this lane is finished with the chunk
+                        done = true;
+                        if (COUNT && ANYHIT) { const uint32_t n = (uint32_t)__popcll(culledLeft); lc.traversals += n; lc.pops += n; lc.innerVisits += n; culledLeft = 0; }
+                    } else {
                         if (ITERS) { if (first_active_lane()) lc.traversals++; }
                         const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
                         cand &= cand - 1;
+                        if (COUNT && ANYHIT) {
+                            const unsigned long long below = culledLeft & ((1ull << k) - 1ull);
+                            const uint32_t n = (uint32_t)__popcll(below);
+                            lc.traversals += n; lc.pops += n; lc.innerVisits += n; culledLeft &= ~below;
+                        }
                         T.enter(S, base + k, o, d, c.distance, lc);
                     }
                 }
@@ -391,7 +410,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
             if (all || runL) {
                 if (!done && T.at_leaf()) {
                     if (ITERS) { if (first_active_lane()) lc.triTests++; }
-                    T.leaf(S, stack, c, lc);
+                    T.template leaf<ANYHIT>(S, stack, c, lc);
                 }
             }
         }
@@ -445,7 +464,18 @@ __device__ __forceinline__ v3 raygen_dir(const CrtFrame& F, int i, int j)
 //   lightDir: the sun at bounce 0, the bounce ray's direction at bounce 1 (kernel_main.cl:181,271) -> from `bounce`.
 struct PathState { v3 o, d, result; float energy; };
 
-__device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest& c, PathState& ps, int bounce, float lightY, float lightZ)
+// kernel_main.cl:264: specular = ((1 - roughness) * ndl * shadow) * specularColor * ndl, x component (a splat)
+__device__ __forceinline__ float specular_x(float ndl, float shadow)
+{
+    const float sp = ((1.0f - 0.5f) * ndl) * shadow;
+    return (sp * 0.2f) * ndl;
+}
+
+// DEFER_ENERGY (CRT_RENDER_SHADOWS): leave `energy *= specular` to the caller, which first traces the shadow ray
+// from the new ray origin; `ndlOut` receives the clamped n.l that decides whether the shadow factor is observable.
+template <bool DEFER_ENERGY = false>
+__device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest& c, PathState& ps, int bounce, float lightY, float lightZ,
+                                             float* ndlOut = nullptr)
 {
     const float UcharToFloat01 = 1.0f / 255.0f;
     if (c.distance > 99998.0f) {
@@ -493,9 +523,6 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
     const v3 color = scale3(mk3((float)cr, (float)cg, (float)cb), UcharToFloat01);
     const v3 point = add3(mo, scale3(md, c.hit.t));
 
-    const v3 specularColor = mk3(0.2f, 0.2f, 0.2f);
-    const float roughness = 0.5f;
-    const float shadow = 1.0f;
 
     ps.o = add3(point, scale3(normal, 0.01f));
     ps.d = reflect3(ps.d, normal);
@@ -503,12 +530,11 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
     float ndl = dot3(normal, neg3(light));
     const v3 ambient = mul3(scale3(atm, fmaxf(0.0f - ndl, 0.1f)), color);
     ndl = fmaxf(ndl, 0.0f);
-    const float sp = ((1.0f - roughness) * ndl) * shadow;
-    const v3 specular = scale3(mul3(mk3(sp, sp, sp), specularColor), ndl);
     // pow(x, shininess) with shininess == 1.0f (kernel_main.cl:250) is exactly x
     const float sl = (ndl * fmaxf(dot3(reflect3(neg3(light), normal), md), 0.0f)) * 0.2f;
 
     ps.result = add3(ps.result, add3(add3(scale3(scale3(color, ndl), ps.energy), ambient), mk3(sl, sl, sl)));
-    ps.energy = ps.energy * specular.x;
+    if (DEFER_ENERGY) *ndlOut = ndl;
+    else ps.energy = ps.energy * specular_x(ndl, 1.0f);      // shadow = 1.0f (kernel_main.cl:258: no shadow ray upstream)
     return true;
 }

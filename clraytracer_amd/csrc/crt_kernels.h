@@ -26,13 +26,13 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 __device__ __forceinline__ void flush_counters(const LaneCounters& lc, unsigned long long* g)
 {
     // every lane of the wave must call this (inactive pixels contribute zeros)
-    uint32_t s[11] = { lc.rays, lc.primary, lc.secondary, lc.hits, lc.misses, lc.traversals, lc.pops,
-                       lc.innerVisits, lc.triTests, lc.capHits, lc.stackOverflows };
+    uint32_t s[13] = { lc.rays, lc.primary, lc.secondary, lc.hits, lc.misses, lc.traversals, lc.pops,
+                       lc.innerVisits, lc.triTests, lc.capHits, lc.stackOverflows, lc.shadowRays, lc.shadowHits };
     uint32_t mx = wave_max(lc.maxStack);
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
+    for (int k = 0; k < 13; ++k) {
         uint32_t t = wave_sum(s[k]);
-        if ((threadIdx.x & 63) == 0 && t) atomicAdd(&g[k], (unsigned long long)t);
+        if ((threadIdx.x & 63) == 0 && t) atomicAdd(&g[k < 11 ? k : k + 1], (unsigned long long)t);   // [11] is maxStack
     }
     if ((threadIdx.x & 63) == 0) atomicMax(&g[11], (unsigned long long)mx);
 }
@@ -41,6 +41,7 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
 {
     lc.rays = lc.primary = lc.secondary = lc.hits = lc.misses = 0;
     lc.traversals = lc.pops = lc.innerVisits = lc.triTests = lc.capHits = lc.stackOverflows = lc.maxStack = 0;
+    lc.shadowRays = lc.shadowHits = 0;
 }
 
 
@@ -151,7 +152,11 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
 // round-trip disappears. One thread per pixel, both bounces.
 // STAMP (diagnostic build only, CRT_RENDER_STAMPS): every wave records start/end s_memrealtime (100 MHz),
 // its s_memtime cycle count and XCC/HW ids into a buffer nothing else reads.
-template <bool COUNT, bool STAMP = false>
+// SHADOW (CRT_RENDER_SHADOWS, an extension: upstream only threads the factor through, kernel_main.cl:256-258,264):
+// after the first hit a shadow ray (new ray origin, -lightDir) decides `shadow` in `energy *= specular`. Traced only
+// where it is observable: at bounce 0 (the energy after bounce 1 is never read) and when n.l > 0 (otherwise the
+// product is 0 whatever the shadow factor).
+template <bool COUNT, bool STAMP = false, bool SHADOW = false>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                               unsigned long long* __restrict__ counters)
 {
@@ -172,9 +177,19 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
             Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, lc);
-            bool cont = shade_bounce(S, c, ps, bounce, F.lightY, F.lightZ);
+            float ndl = 0.0f;
+            bool cont = shade_bounce<SHADOW>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
             if (!cont) break;
+            if (SHADOW) {
+                float shadow = 1.0f;
+                if (bounce == 0 && ndl > 0.0f) {
+                    if (COUNT) { lc.rays++; lc.shadowRays++; }
+                    const Closest sc = closest_hit<COUNT, false, GlobalPairLoader, true>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc);
+                    if (sc.anyHit) { shadow = 0.0f; if (COUNT) lc.shadowHits++; }
+                }
+                ps.energy = ps.energy * specular_x(ndl, shadow);
+            }
         }
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
     }

@@ -73,6 +73,7 @@ struct State {
 };
 State g;
 
+#define CRT_NUM_COUNTERS 14
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return (int)e_; } } while (0)
 #define RCCHK(x) do { int r_ = (x); if (r_ != CRT_OK) { return r_; } } while (0)
 
@@ -263,11 +264,12 @@ int collect_set(EventSet& es)
     }
     if (es.seq >= g.msSeq) { memcpy(g.ms, ms, sizeof ms); g.msSeq = es.seq; }
     if (es.flags & CRT_RENDER_COUNTERS) {
-        unsigned long long c[12];
+        unsigned long long c[CRT_NUM_COUNTERS];
         HIPCHK(hipMemcpy(c, g.counters, sizeof c, hipMemcpyDeviceToHost));
         CrtCounters& o = g.lastCounters;
         o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
         o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
+        o.shadowRays = c[12]; o.shadowHits = c[13];
     }
     es.pending = false;
     return CRT_OK;
@@ -345,7 +347,7 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.devInstances, CRT_MAX_INSTANCES * sizeof(CrtDevInstance)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
-    HIPCHK(hipMalloc(&g.counters, 12 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g.counters, CRT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
     HIPCHK(hipMalloc(&g.queues, sizeof(CrtQueues)));
     HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
@@ -563,7 +565,7 @@ static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool
 static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid, FrameSlot& fs)
 {
     const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
-    if (count) HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), fs.stream));
+    if (count) HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), fs.stream));
     if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
         unsigned waves = grid;
         if (g.persistent) {
@@ -608,6 +610,9 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
             crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
         }
+    } else if (flags & CRT_RENDER_SHADOWS) {
+        if (count) crt_trace_kernel<true, false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
+        else crt_trace_kernel<false, false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
     } else if (count) {
         crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
     } else {
@@ -633,6 +638,7 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     // overlap (each slot has its own stream, output buffer and launch lists). Everything else -- synchronous frames,
     // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
     const bool variant = g.persistent || g.wavefront || g.ldsTiles;
+    if ((flags & CRT_RENDER_SHADOWS) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
     const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
                         && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
     int slot = 0;
@@ -701,17 +707,18 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     CrtRayHit* dH = reinterpret_cast<CrtRayHit*>(dD + 3 * (size_t)n);
     HIPCHK(hipMemcpyAsync(dO, origins, rayBytes, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(dD, dirs, rayBytes, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemsetAsync(g.counters, 0, 12 * sizeof(unsigned long long), g.stream));
+    HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), g.stream));
     CrtDevScene S; fill_scene(S, numInstances);
     crt_query_kernel<<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dH, sizeof(CrtRayHit) * (size_t)n, hipMemcpyDeviceToHost, g.stream));
-    unsigned long long c[12];
+    unsigned long long c[CRT_NUM_COUNTERS];
     HIPCHK(hipMemcpyAsync(c, g.counters, sizeof c, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     CrtCounters& o = g.lastCounters;
     o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
     o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
+        o.shadowRays = c[12]; o.shadowHits = c[13];
     return CRT_OK;
 }
 

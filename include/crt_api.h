@@ -41,7 +41,9 @@ enum {
     CRT_RENDER_WRITE_RAYS  = 2,   /* materialise the RayGen buffer (kernel_main.cl:277-287) in HBM */
     CRT_RENDER_ASYNC       = 4,   /* do not wait for completion (the reference always clFinish()es); see crt_render */
     CRT_RENDER_COUNTERS    = 8,   /* instrumented launch that fills the work counters (slower) */
-    CRT_RENDER_STAMPS      = 16   /* diagnostic launch: per-wave start/end clock stamps (crt_debug_read_stamps) */
+    CRT_RENDER_STAMPS      = 16,  /* diagnostic launch: per-wave start/end clock stamps (crt_debug_read_stamps) */
+    CRT_RENDER_SHADOWS     = 32   /* extension (kernel_main.cl:256-258 is a TODO upstream): one any-hit shadow ray from the first
+                                     hit towards the sun sets the `shadow` factor of kernel_main.cl:264; see DESIGN.md */
 };
 
 /* Device work counters of the last CRT_RENDER_COUNTERS / crt_query_hits launch. Same meaning as
@@ -49,6 +51,7 @@ enum {
 typedef struct CrtCounters {
     uint64_t rays, primary, secondary, hits, misses;
     uint64_t traversals, pops, innerVisits, triTests, capHits, stackOverflows, maxStack;
+    uint64_t shadowRays, shadowHits;   /* CRT_RENDER_SHADOWS: shadow rays traced (also in `rays`) / found occluded */
 } CrtCounters;
 
 /* Renderer.cpp:122-193 (InitializeOpenCL + buffer creation) and ResourceManager.cpp:145-178

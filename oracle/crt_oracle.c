@@ -163,8 +163,9 @@ float orc_intersect_aabb(const float o[3], const float invDir[3], const float bm
 static uint32_t* g_visit_counts = NULL;
 void orc_set_visit_counts(uint32_t* counts) { g_visit_counts = counts; }
 
-static int intersect_bvh(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode, const CrtTri* tris,
-                         Triout* out, OrcStats* st)
+/* anyHit != 0 (shadow-ray extension, orc_trace_shadows): return at the first triangle that passes. */
+static int intersect_bvh_ex(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode, const CrtTri* tris,
+                            Triout* out, OrcStats* st, int anyHit)
 {
     int32_t nodesToVisit[CRT_STACK_DEPTH];
     memset(nodesToVisit, 0, sizeof nodesToVisit);
@@ -184,6 +185,7 @@ static int intersect_bvh(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode, co
                 for (int i = (int)node->leftFirst, end = i + (int)node->triCount; i < end; ++i) {
                     st->triTests++;
                     intersection |= intersect_triangle(ray, tris + i, out, i);
+                    if (anyHit && intersection) return 1;
                 }
                 break;
             }
@@ -215,6 +217,12 @@ static int intersect_bvh(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode, co
         }
     }
     return intersection;
+}
+
+static int intersect_bvh(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode, const CrtTri* tris,
+                         Triout* out, OrcStats* st)
+{
+    return intersect_bvh_ex(ray, nodes, rootNode, tris, out, st, 0);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -337,12 +345,30 @@ static inline Closest closest_hit(const OrcScene* s, Ray ray, uint32_t numMeshes
     return c;
 }
 
+/* Shadow-ray EXTENSION (no upstream code: kernel_main.cl:256-258 is a commented-out TODO). The instance loop of
+ * kernel_main.cl:198-217 for the ray (origin, dir) with t = Infinite, stopping at the first triangle that passes. */
+static int occluded(const OrcScene* s, Ray ray, uint32_t numMeshes, OrcStats* st)
+{
+    for (uint32_t i = 0; i < numMeshes; ++i) {
+        Triout triout;
+        triout.t = 99999.0f; triout.triIndex = 0; triout.u = 0.0f; triout.v = 0.0f;
+        const CrtMeshInstance* instance = s->instances + i;
+        float o4[4], d4[4];
+        matmul4(&instance->inverseTransform, ray.origin.x, ray.origin.y, ray.origin.z, 1.0f, o4);
+        matmul4(&instance->inverseTransform, ray.direction.x, ray.direction.y, ray.direction.z, 0.0f, d4);
+        Ray mRay = { f3_make(o4[0], o4[1], o4[2]), f3_make(d4[0], d4[1], d4[2]) };
+        if (intersect_bvh_ex(mRay, s->nodes, s->roots[instance->meshIndex], s->tris, &triout, st, 1)) return 1;
+    }
+    return 0;
+}
+
 static void stats_add(OrcStats* a, const OrcStats* b)
 {
     a->rays += b->rays; a->primary += b->primary; a->secondary += b->secondary;
     a->hits += b->hits; a->misses += b->misses; a->traversals += b->traversals;
     a->pops += b->pops; a->innerVisits += b->innerVisits; a->triTests += b->triTests;
     a->capHits += b->capHits; a->stackOverflows += b->stackOverflows;
+    a->shadowRays += b->shadowRays; a->shadowHits += b->shadowHits;
     if (b->maxStack > a->maxStack) a->maxStack = b->maxStack;
 }
 
@@ -350,7 +376,7 @@ static void stats_add(OrcStats* a, const OrcStats* b)
  * kernel_main.cl:164-275  Trace, one pixel
  * ---------------------------------------------------------------------------------------- */
 static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, float lightY, float lightZ,
-                        float out[4], OrcStats* st)
+                        float out[4], OrcStats* st, int shadows)
 {
     Ray ray = { f3_make(args->cameraPos[0], args->cameraPos[1], args->cameraPos[2]), rayDir };
     f3 lightDir = f3_make(0.0f, lightY, lightZ);
@@ -405,11 +431,19 @@ static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, 
         ray.origin = f3_add(ray.origin, f3_scale(normal, 0.01f));
         ray.direction = f3_reflect(ray.direction, normal);
 
-        float shadow = 1.0f;
+        float shadow = 1.0f; /* upstream: "todo shadow for only directional light" (kernel_main.cl:258) */
 
         float ndl = f3_dot(normal, f3_neg(lightDir));
         f3 ambient = f3_mul(f3_scale(atmosphericLight, fmaxf(0.0f - ndl, 0.1f)), color);
         ndl = fmaxf(ndl, 0.0f);
+        /* EXTENSION (shadows != 0): the commented-out `shadowRay = CreateRay(ray.origin, -lightDir)` of
+         * kernel_main.cl:257. `shadow` only scales `specular`, i.e. the energy of the NEXT bounce, so the ray is traced
+         * only where that is observable: at the first bounce and when ndl > 0 (else the product is 0 or NaN anyway). */
+        if (shadows && numBounces == 0 && ndl > 0.0f) {
+            Ray shadowRay = { ray.origin, f3_neg(lightDir) };
+            st->rays++; st->shadowRays++;
+            if (occluded(s, shadowRay, args->numMeshes, st)) { shadow = 0.0f; st->shadowHits++; }
+        }
         float sp = ((1.0f - roughness) * ndl) * shadow;
         f3 specular = f3_scale(f3_mul(f3_make(sp, sp, sp), specularColor), ndl);
         float sl = (ndl * powf(fmaxf(f3_dot(f3_reflect(f3_neg(lightDir), normal), c.meshRay.direction), 0.0f), shininess)) * 0.2f;
@@ -427,6 +461,12 @@ static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, 
 void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                int row0, int row1, float* out, OrcStats* stats, int nthreads)
 {
+    orc_trace_ex(s, args, rays, width, height, row0, row1, out, stats, nthreads, 0);
+}
+
+void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
+                  int row0, int row1, float* out, OrcStats* stats, int nthreads, int shadows)
+{
     (void)height;
     const float lightY = (float)sin((double)args->sunAngle);
     const float lightZ = (float)cos((double)args->sunAngle);
@@ -440,7 +480,7 @@ void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, i
             for (int i = 0; i < width; ++i) {
                 size_t idx = (size_t)j * (size_t)width + (size_t)i;
                 f3 d = f3_make(rays[3 * idx], rays[3 * idx + 1], rays[3 * idx + 2]);
-                trace_pixel(s, args, d, lightY, lightZ, out + 4 * idx, &st);
+                trace_pixel(s, args, d, lightY, lightZ, out + 4 * idx, &st, shadows);
             }
         }
 #pragma omp critical
@@ -463,7 +503,7 @@ void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* r
             OrcStats st; memset(&st, 0, sizeof st);
             float px[4];
             f3 d = f3_make(rays[3 * idx], rays[3 * idx + 1], rays[3 * idx + 2]);
-            trace_pixel(s, args, d, lightY, lightZ, px, &st);
+            trace_pixel(s, args, d, lightY, lightZ, px, &st, 0);
             innerOut[idx] = (uint32_t)st.innerVisits;
             triOut[idx] = (uint32_t)st.triTests;
         }

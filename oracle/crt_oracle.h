@@ -72,6 +72,7 @@ typedef struct OrcStats {
     uint64_t capHits;               /* traversals stopped by the 250-pop cap */
     uint64_t stackOverflows;        /* pushes beyond 32 entries */
     uint64_t maxStack;
+    uint64_t shadowRays, shadowHits; /* orc_trace_ex(shadows=1): shadow rays traced (also counted in `rays`) / occluded */
 } OrcStats;
 
 /* ---- scalar helpers / KATs ---- */
@@ -104,6 +105,12 @@ void orc_raygen(float* rays, int width, int height, const float invView[16], con
  * `out` is the full-frame RGBA float buffer (only the requested rows are written). */
 void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                int row0, int row1, float* out, OrcStats* stats, int nthreads);
+/* orc_trace plus the shadow-ray EXTENSION (shadows != 0). Upstream has no shadow ray -- kernel_main.cl:256-258 is a
+ * commented-out TODO with `shadow = 1.0f` threaded into kernel_main.cl:264 -- so this mode has no reference
+ * behaviour to match; it is defined here (origin = the bounce ray's origin, direction = -lightDir, any-hit over the
+ * same instance loop, traced at the first bounce when n.l > 0) and the HIP path must match it bit for bit. */
+void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
+                  int row0, int row1, float* out, OrcStats* stats, int nthreads, int shadows);
 void orc_postprocess(float* rgba, int width, int height, int row0, int row1);
 /* Analysis helper: per-pixel inner visits / triangle tests (both bounces) of a full frame. */
 void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,

@@ -16,7 +16,8 @@ class OrcScene(C.Structure):
 
 class OrcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "primary", "secondary", "hits", "misses", "traversals", "pops",
-                                          "innerVisits", "triTests", "capHits", "stackOverflows", "maxStack")]
+                                          "innerVisits", "triTests", "capHits", "stackOverflows", "maxStack",
+                                          "shadowRays", "shadowHits")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -55,6 +56,9 @@ def lib():
         L.orc_trace.restype = None
         L.orc_trace.argtypes = [C.POINTER(OrcScene), C.POINTER(CrtTraceArgs), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.POINTER(OrcStats), C.c_int]
+        L.orc_trace_ex.restype = None
+        L.orc_trace_ex.argtypes = [C.POINTER(OrcScene), C.POINTER(CrtTraceArgs), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.POINTER(OrcStats), C.c_int, C.c_int]
         L.orc_postprocess.restype = None; L.orc_postprocess.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_closest_hits.restype = None
         L.orc_closest_hits.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(OrcStats), C.c_int]
@@ -89,7 +93,7 @@ class Oracle:
         lib().orc_raygen(rays.ctypes.data, width, height, p1, p2)
         return rays
 
-    def trace(self, rays, cam_pos, sun_angle, row0=0, row1=None):
+    def trace(self, rays, cam_pos, sun_angle, row0=0, row1=None, shadows=False):
         h, w, _ = rays.shape
         row1 = h if row1 is None else row1
         out = np.zeros((h, w, 4), np.float32)
@@ -98,7 +102,8 @@ class Oracle:
         args.time = 0.0; args.numMeshes = self.s.numInstances; args.sunAngle = float(sun_angle)
         st = OrcStats()
         rays = np.ascontiguousarray(rays, np.float32)
-        lib().orc_trace(C.byref(self.s), C.byref(args), rays.ctypes.data, w, h, row0, row1, out.ctypes.data, C.byref(st), self.nthreads)
+        lib().orc_trace_ex(C.byref(self.s), C.byref(args), rays.ctypes.data, w, h, row0, row1, out.ctypes.data, C.byref(st), self.nthreads,
+                           1 if shadows else 0)
         return out, st.as_dict()
 
     def postprocess(self, img, row0=0, row1=None):

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false>"
+    kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false"
     base = os.path.join(ROOT, "gpurun_out")
     out = {"tag": tag, "kernel": kern, "kernel_stats": [], "counters": {}, "bench_line": None}
     def newest(pattern):
@@ -25,6 +25,20 @@ def main():
         for r in csv.DictReader(open(f)):
             out["kernel_stats"].append({"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                         "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])})
+    # launch overlap (frames in flight): per-launch durations vs the union of the launch intervals, from the trace itself
+    for f in newest(os.path.join(base, f"prof_{tag}_stats", "*", "*_kernel_trace.csv")):
+        iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"])
+        if iv:
+            union, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+            for a, b in iv[1:]:
+                if a > cur_e:
+                    union += cur_e - cur_s; cur_s, cur_e = a, b
+                else:
+                    cur_e = max(cur_e, b)
+            union += cur_e - cur_s
+            total = sum(b - a for a, b in iv)
+            out["launch_overlap"] = {"launches": len(iv), "mean_launch_us": total / len(iv) / 1e3, "busy_us_per_launch": union / len(iv) / 1e3,
+                                     "mean_launches_in_flight": total / max(1, union)}
     log = os.path.join(base, f"prof_{tag}_stats.log")
     if os.path.exists(log):
         for line in open(log):
@@ -73,6 +87,11 @@ def main():
         f.write("## --kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
         for k in sorted(out["kernel_stats"], key=lambda r: -r["pct"]):
             f.write(f"| `{k['name'][:90]}` | {k['calls']} | {k['avg_ns'] / 1e3:.1f} | {k['min_ns'] / 1e3:.1f} | {k['max_ns'] / 1e3:.1f} | {k['pct']:.2f} |\n")
+        if out.get("launch_overlap"):
+            o = out["launch_overlap"]
+            f.write(f"\n`{kern}` launches in the trace: {o['launches']}, mean launch duration {o['mean_launch_us']:.1f} us, device time with at least one "
+                    f"launch running {o['busy_us_per_launch']:.1f} us per launch, mean launches in flight {o['mean_launches_in_flight']:.2f} "
+                    f"(bench.py: `roofline.launch_duration_ms` / `kernel_ms.device_time_per_frame` / `launches_in_flight`).\n")
         f.write(f"\n## PMC passes (mean per launch of `{kern}`; one counter group per run, 5-step runs)\n\ndispatch: {meta}\n\n| counter | mean per launch | launches |\n|---|---|---|\n")
         for k in sorted(out["counters"]):
             f.write(f"| {k} | {out['counters'][k]['mean_per_launch']:.4g} | {out['counters'][k]['launches']} |\n")
