@@ -110,6 +110,8 @@ HOST_API = {
     "crth_get_camera": (None, [_fp, _fp, _fp]),
     "crth_resize": (None, [C.c_int, C.c_int]),
     "crth_set_postprocess": (None, [C.c_int]),
+    "crth_set_shadows": (None, [C.c_int]),
+    "crth_set_pipelined": (None, [C.c_int]),
     "crth_set_row_bands": (None, [C.c_int, C.c_int, C.c_int]),
     "crth_render": (C.c_uint, [_f]),
     "crth_map_output": (_vp, []),

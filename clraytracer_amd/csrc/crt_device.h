@@ -46,8 +46,11 @@
 // (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load. A 16-slot LDS
 // stack with the upper slots in scratch was measured too: more waves fit, but 5 -> 6 -> 8 waves/SIMD changed nothing.)
 typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
-#define CRT_STACK_WRITE(slot, v) do { stack[((slot) & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK] = (v); } while (0)
-#define CRT_STACK_READ(slot, dst) do { dst = stack[((slot) & (CRT_STACK_DEPTH - 1)) * CRT_BLOCK]; } while (0)
+#ifndef CRT_EXP_STACK_SLOTS            // experiment hook (tools/ab_define.sh): fewer LDS slots = more waves per CU; NOT upstream semantics
+#define CRT_EXP_STACK_SLOTS CRT_STACK_DEPTH
+#endif
+#define CRT_STACK_WRITE(slot, v) do { stack[((slot) & (CRT_EXP_STACK_SLOTS - 1)) * CRT_BLOCK] = (v); } while (0)
+#define CRT_STACK_READ(slot, dst) do { dst = stack[((slot) & (CRT_EXP_STACK_SLOTS - 1)) * CRT_BLOCK]; } while (0)
 #define CRT_MAX_SPLIT 96   // per XCD and frame: heaviest tiles traced as four 4x4-pixel waves instead of one 8x8 wave
 #define CRT_MAX_SPLIT_PIPELINED 4  // with frames in flight the tail is hidden by the next frame: split only the very heaviest
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside

@@ -160,7 +160,7 @@ template <bool COUNT, bool STAMP = false, bool SHADOW = false>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                               unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
     crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_ker
                                                                 unsigned long long* __restrict__ counters,
                                                                 CrtBounceRay* __restrict__ queue, uint32_t* __restrict__ queueCount)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
     crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     int px, py;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kern
                                                                unsigned long long* __restrict__ counters,
                                                                const CrtBounceRay* __restrict__ queue, const uint32_t* __restrict__ queueCount)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
     crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     const uint32_t n = *queueCount;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
     crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;

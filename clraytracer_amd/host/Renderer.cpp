@@ -16,6 +16,7 @@ namespace {
     Camera camera;
     bool deviceReady = false;
     bool postProcess = true;   // upstream always runs PostProcess (Renderer.cpp:360-363)
+    bool shadows = false, pipelined = false;
     float timeSeconds = 0.0f;
     unsigned frameIndex = 0;
     int lastError = 0;
@@ -46,6 +47,8 @@ namespace {
 const Camera& Renderer::GetCamera() { return camera; }
 Camera& Renderer::EditCamera() { return camera; }
 void Renderer::SetPostProcess(bool enabled) { postProcess = enabled; }
+void Renderer::SetShadows(bool enabled) { shadows = enabled; }
+void Renderer::SetPipelined(bool enabled) { pipelined = enabled; }
 void Renderer::SetTime(float seconds) { timeSeconds = seconds; }
 int Renderer::LastError() { return lastError ? lastError : ResourceManager::LastError(); }
 float Renderer::LastFrameMs() { return deviceReady ? crt_last_kernel_ms(0) : -1.0f; }
@@ -159,7 +162,7 @@ unsigned Renderer::Render(float sunAngle)
     CrtTraceArgs args;
     args.cameraPos[0] = camera.position.x; args.cameraPos[1] = camera.position.y; args.cameraPos[2] = camera.position.z;
     args.time = timeSeconds; args.numMeshes = g_NumMeshInstances; args.sunAngle = sunAngle;
-    const int flags = postProcess ? CRT_RENDER_POSTPROCESS : 0;
+    const int flags = (postProcess ? CRT_RENDER_POSTPROCESS : 0) | (shadows ? CRT_RENDER_SHADOWS : 0) | (pipelined ? CRT_RENDER_ASYNC : 0);
     if (!check(crt_render(&args, &camera.inverseView.m[0][0], &camera.inverseProjection.m[0][0], flags), "crt_render")) return 0;
     return ++frameIndex;
 }

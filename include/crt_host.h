@@ -42,6 +42,8 @@ void crth_set_camera(const float position[3], const float front[3]); /* Camera p
 void crth_get_camera(float invView[16], float invProj[16], float position[3]);
 void crth_resize(int width, int height);                     /* Renderer::OnWindowResize */
 void crth_set_postprocess(int enabled);
+void crth_set_shadows(int enabled);                          /* Renderer::SetShadows (extension) */
+void crth_set_pipelined(int enabled);                        /* Renderer::SetPipelined (frames in flight) */
 void crth_set_row_bands(int bandRows, int rank, int nRanks);
 unsigned crth_render(float sunAngle);                        /* Renderer::Render: frame index, 0 on failure */
 const float* crth_map_output(void);                          /* Renderer::MapOutput */

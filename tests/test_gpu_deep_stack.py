@@ -1,0 +1,97 @@
+"""Hazard H2: upstream's traversal stack is `int nodesToVisit[32]` with no overflow check (kernel_main.cl:126,154).
+The oracle pins the undefined overflow as "slot index wraps modulo 32"; the HIP path keeps most slots in LDS and the
+rest in a per-wave-slot overflow area and must reproduce exactly that -- including a hand-built 48-level caterpillar
+tree whose rays push 47 far children before the first pop, and the 250-pop cap on a tree deeper than the cap."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from clraytracer_amd import _lib, driver, scenes
+import oracle_lib
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def half(x):
+    return np.asarray(x, np.float16).view(np.uint16)
+
+
+def caterpillar(levels, reverse=False):
+    """Level k holds one leaf triangle T_k; inner node N_k = {inner N_{k+1} (near for a +z ray), leaf T_k (far)}.
+    Deeper triangles are closer to the camera, so a ray descends all the way down pushing every leaf on the way."""
+    tris = np.zeros(levels, _lib.TRI_DTYPE)
+    for k in range(levels):
+        step = min(0.75, 90.0 / levels)                     # every level stays in front of the camera
+        z = 100.0 - step * k
+        s = 60.0                                            # big enough that every level covers the view
+        if reverse:
+            z = 100.0 - step * (levels - 1 - k)
+        tris["v0"][k] = (-s, -s, z); tris["v1"][k] = (s, -s, z + 0.1); tris["v2"][k] = (0.0, s, z + 0.2)
+        tris["uv"][k] = half([0, 0, 1, 0, 0.5, 1])
+        tris["mat"][k] = k % 2
+        tris["n"][k] = half([0, 0, -1] * 3)
+    for k in range(levels):
+        c = (tris["v0"][k] + tris["v1"][k] + tris["v2"][k]) * np.float32(0.333333)
+        tris["cx"][k], tris["cy"][k], tris["cz"][k] = c
+    nodes = np.zeros(2 * levels - 1, _lib.NODE_DTYPE)
+
+    def tri_box(k0, k1):
+        v = np.concatenate([tris[f][k0:k1] for f in ("v0", "v1", "v2")])
+        return v.min(0), v.max(0)
+
+    # node 0 = root N_0; pair k at (2k+1, 2k+2) = (N_{k+1} or the last leaf, leaf T_k)
+    lo, hi = tri_box(0, levels)
+    nodes["min"][0], nodes["max"][0], nodes["leftFirst"][0], nodes["triCount"][0] = lo, hi, 1, 0
+    for k in range(levels - 1):
+        a, b = 2 * k + 1, 2 * k + 2
+        lo, hi = tri_box(k + 1, levels)
+        if k + 1 == levels - 1:                              # deepest level: both children are leaves
+            nodes["min"][a], nodes["max"][a], nodes["leftFirst"][a], nodes["triCount"][a] = lo, hi, levels - 1, 1
+        else:
+            nodes["min"][a], nodes["max"][a], nodes["leftFirst"][a], nodes["triCount"][a] = lo, hi, 2 * (k + 1) + 1, 0
+        lo, hi = tri_box(k, k + 1)
+        nodes["min"][b], nodes["max"][b], nodes["leftFirst"][b], nodes["triCount"][b] = lo, hi, k, 1
+    return tris, nodes
+
+
+@pytest.mark.parametrize("levels,reverse", [(20, False), (31, False), (34, False), (48, False), (48, True), (300, False)])
+def test_hand_built_deep_tree_matches_oracle(levels, reverse, nthreads):
+    sc = scenes.get("tiny")
+    hip = _lib.hip()
+    W, H = 96, 64
+    with driver.Session(W, H, device=0) as s:
+        s.load_scene(sc)                                     # materials, textures, skybox
+        a = dict(s.arenas())
+        tris, nodes = caterpillar(levels, reverse)
+        roots = np.zeros(1, np.uint32)
+        inst = np.zeros(1, _lib.INSTANCE_DTYPE)
+        inst["inv"][0] = np.eye(4, dtype=np.float32)
+        inst["meshIndex"], inst["materialStart"] = 0, 0
+        assert hip.crt_upload_triangles(tris.ctypes.data, 0, tris.nbytes) == 0
+        assert hip.crt_upload_bvh_roots(roots.ctypes.data, 0, 1) == 0
+        assert hip.crt_upload_bvh_nodes(nodes.ctypes.data, 0, nodes.nbytes) == 0
+        assert hip.crt_upload_instances(inst.ctypes.data, 0, 1) == 0
+        a.update(tris=tris, nodes=nodes, roots=roots, instances=inst)
+        orc = oracle_lib.Oracle(a, nthreads=nthreads)
+        s.set_camera((0.3, 0.2, -40.0), scenes._normalize((0.0, 0.0, 1.0)))
+        iv, ip, pos = s.camera()
+        args = _lib.CrtTraceArgs()
+        args.cameraPos[0], args.cameraPos[1], args.cameraPos[2] = [float(x) for x in pos]
+        args.time, args.numMeshes, args.sunAngle = 0.0, 1, float(sc.sun_angle)
+        fp = C.POINTER(C.c_float)
+        ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle)
+        for flags in (8, 0, 4, 4, 8 | 32):
+            assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), flags) == 0
+            if flags & 32:
+                ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle, shadows=True)
+            assert np.array_equal(bits(s.read_output()), bits(ref)), (levels, flags)
+            if flags & 8:
+                assert s.counters() == st, (levels, flags)
+        if not reverse:
+            assert st["maxStack"] == min(levels - 1, 249) or levels > 250
+        if levels in (34, 48) and not reverse:
+            assert st["stackOverflows"] > 0
+        if levels == 300:
+            assert st["capHits"] > 0

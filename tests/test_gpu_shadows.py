@@ -37,6 +37,11 @@ def test_shadow_frames_match_oracle(name, size, nthreads):
         assert np.array_equal(bits(s.read_output()), bits(plain)) and s.counters() == st0
         if st["shadowHits"]:
             assert not np.array_equal(bits(ref), bits(plain))
+        # the mirrored Renderer: SetShadows / SetPipelined
+        s.render(postprocess=False, shadows=True, pipelined=True); s.render(postprocess=False, shadows=True, pipelined=True)
+        assert np.array_equal(bits(s.output()), bits(ref))
+        s.render(postprocess=False)
+        assert np.array_equal(bits(s.output()), bits(plain))
 
 
 def test_shadows_many_instances(nthreads):
