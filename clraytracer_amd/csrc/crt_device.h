@@ -37,20 +37,53 @@
 #define CRT_HOT_PAIRS 1024   // pair indices below this are the trees' top levels (64 KiB: the LDS-staged hot tiles)
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
 #ifndef CRT_WAVES_PER_SIMD
-#define CRT_WAVES_PER_SIMD 5
+#define CRT_WAVES_PER_SIMD 5   // 20 waves per CU is what 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
 #endif
-//  // 20 waves per CU is what the 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
-// Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126) in LDS, 32 slots x 4 B per lane = 8 KiB per
-// wave; slot s of lane l lives at stack[s * 64 + l], so a wave's ds_read/ds_write_b32 is conflict-free. Slot indices
-// wrap modulo 32 where upstream's array would overflow. 160 KiB of LDS hold the stacks of 20 waves per CU.
-// (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load. A 16-slot LDS
-// stack with the upper slots in scratch was measured too: more waves fit, but 5 -> 6 -> 8 waves/SIMD changed nothing.)
+#define CRT_WAVES_PER_SIMD_WIDE 6   // the flavour for frames in flight: 6400-B LDS stacks, 80 VGPRs (CrtStackT below)
+// Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126), slot indices wrapping modulo 32 where
+// upstream's array would overflow. Two flavours (template parameter LDS_SLOTS of CrtStackT):
+//  * 32: every slot in LDS -- slot s of lane l at lds[s * 64 + l], so a wave's ds_read/ds_write_b32 is conflict-free;
+//    8 KiB per wave, 20 waves per CU (5 per SIMD, 96 VGPRs). Used for synchronous frames, where the latency of the
+//    slowest wave decides the frame.
+//  * 25: slots 0..24 in LDS (6400 B per wave: 24 waves per CU = 6 per SIMD, 80 VGPRs) and slots 25..31, which no
+//    scene here has ever reached (observed depth <= 15), in a global overflow area indexed by the hardware slot the
+//    wave occupies (XCC, SE, SH, CU, SIMD, wave slot from HW_ID / XCC_ID): waves resident at the same time never
+//    share an entry, whatever kernel or stream they belong to, and an entry is always written (push) before it is
+//    read (pop) within one traversal, so the area needs no initialisation. Used for frames in flight, where
+//    throughput decides: +6 % there, -9 % on a synchronous frame (a few spills in the hot loop).
+// (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load.)
 typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
-#ifndef CRT_EXP_STACK_SLOTS            // experiment hook (tools/ab_define.sh): fewer LDS slots = more waves per CU; NOT upstream semantics
-#define CRT_EXP_STACK_SLOTS CRT_STACK_DEPTH
-#endif
-#define CRT_STACK_WRITE(slot, v) do { stack[((slot) & (CRT_EXP_STACK_SLOTS - 1)) * CRT_BLOCK] = (v); } while (0)
-#define CRT_STACK_READ(slot, dst) do { dst = stack[((slot) & (CRT_EXP_STACK_SLOTS - 1)) * CRT_BLOCK]; } while (0)
+#define CRT_LDS_SLOTS_WIDE 25                      // LDS slots of the 6-waves/SIMD flavour
+#define CRT_OVF_SLOTS (CRT_STACK_DEPTH - CRT_LDS_SLOTS_WIDE)
+#define CRT_OVF_WAVE_BITS 17                       // wave slot 4 | SIMD 2 | CU+SH 5 | SE 3 | XCC 3
+#define CRT_OVF_WORDS (((size_t)1 << CRT_OVF_WAVE_BITS) * CRT_OVF_SLOTS * 64)
+__device__ __forceinline__ uint32_t* crt_overflow_slot(uint32_t* base, int k)
+{
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID[3:0]
+    const uint32_t w = (hw & 0xFu) | (((hw >> 4) & 0x3u) << 4) | (((hw >> 8) & 0x1Fu) << 6) | (((hw >> 13) & 0x7u) << 11) | ((xcc & 0x7u) << 14);
+    return base + ((size_t)w * CRT_OVF_SLOTS + (size_t)k) * 64 + (threadIdx.x & 63);
+}
+template <int LDS_SLOTS>
+struct CrtStackT {
+    static_assert(LDS_SLOTS == CRT_STACK_DEPTH || LDS_SLOTS == CRT_LDS_SLOTS_WIDE, "the overflow area is sized for these two");
+    static constexpr int kLdsSlots = LDS_SLOTS;
+    crt_lds_u32_ptr lds;     // this lane's slot 0
+    uint32_t* ovf;           // base of the overflow area (wave-uniform); unused when every slot is in LDS
+    __device__ __forceinline__ void write(int slot, uint32_t v) const
+    {
+        const int s = slot & (CRT_STACK_DEPTH - 1);
+        if (LDS_SLOTS >= CRT_STACK_DEPTH || s < LDS_SLOTS) lds[s * 64] = v;
+        else *crt_overflow_slot(ovf, s - LDS_SLOTS) = v;
+    }
+    __device__ __forceinline__ uint32_t read(int slot) const
+    {
+        const int s = slot & (CRT_STACK_DEPTH - 1);
+        if (LDS_SLOTS >= CRT_STACK_DEPTH || s < LDS_SLOTS) return lds[s * 64];
+        return *crt_overflow_slot(ovf, s - LDS_SLOTS);
+    }
+};
+typedef CrtStackT<CRT_STACK_DEPTH> CrtStack;       // every slot in LDS
 #define CRT_MAX_SPLIT 96   // per XCD and frame: heaviest tiles traced as four 4x4-pixel waves instead of one 8x8 wave
 #define CRT_MAX_SPLIT_PIPELINED 4  // with frames in flight the tail is hidden by the next frame: split only the very heaviest
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
@@ -61,6 +94,7 @@ struct CrtDevScene {
     const uint4* __restrict__ triCold;
     const uint32_t* __restrict__ bigLeaf;
     const uint32_t* __restrict__ rootRefs;
+    uint32_t* stackOverflow;             // CRT_OVF_WORDS words, see CrtStack
     const CrtMeshInstance* __restrict__ instances;
     const struct CrtDevInstance* __restrict__ devInstances;
     const float4* __restrict__ instBounds;   // world-space bounding sphere per instance (xyz, r); r < 0: never cull
@@ -260,11 +294,12 @@ struct Traversal {
         active = false;
     }
     // `while (currentNodeIndex > 0 && protection++ < 250) node = stack[--currentNodeIndex]` (kernel_main.cl:131-133)
-    __device__ __forceinline__ void pop_next(crt_lds_u32_ptr stack, Closest& c, LaneCounters& lc)
+    template <class Stack>
+    __device__ __forceinline__ void pop_next(const Stack& stack, Closest& c, LaneCounters& lc)
     {
         if (sp > 0) {
             if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; finish(c); }
-            else { if (COUNT) lc.pops++; --sp; CRT_STACK_READ(sp, ref); }
+            else { if (COUNT) lc.pops++; --sp; ref = stack.read(sp); }
         } else finish(c);
     }
     // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root
@@ -282,8 +317,8 @@ struct Traversal {
         if (COUNT) { lc.traversals++; lc.pops++; }
     }
     // kernel_main.cl:142-157: fetch the child pair, two slab tests, near child first, far child pushed
-    template <class PairLoader>
-    __device__ __forceinline__ void inner(const CrtDevScene& S, const PairLoader& loadPair, crt_lds_u32_ptr stack, Closest& c, LaneCounters& lc)
+    template <class PairLoader, class Stack>
+    __device__ __forceinline__ void inner(const CrtDevScene& S, const PairLoader& loadPair, const Stack& stack, Closest& c, LaneCounters& lc)
     {
         float4 lmin, lmax, rmin, rmax;
         loadPair(S, ref, lmin, lmax, rmin, rmax);
@@ -300,7 +335,7 @@ struct Traversal {
             ref = nearRef;
             if (dist2 != 1e30f) {
                 if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
-                CRT_STACK_WRITE(sp, farRef);
+                stack.write(sp, farRef);
                 sp++;
                 if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
             }
@@ -308,8 +343,8 @@ struct Traversal {
     }
     // kernel_main.cl:135-140: every triangle of the leaf, then the next pop.
     // ANYHIT (shadow rays): the traversal ends at the first triangle that passes.
-    template <bool ANYHIT = false>
-    __device__ __forceinline__ void leaf(const CrtDevScene& S, crt_lds_u32_ptr stack, Closest& c, LaneCounters& lc)
+    template <bool ANYHIT = false, class Stack = CrtStack>
+    __device__ __forceinline__ void leaf(const CrtDevScene& S, const Stack& stack, Closest& c, LaneCounters& lc)
     {
         const uint32_t first = ref & 0x00FFFFFFu;
         uint32_t n = (ref >> 24) & 0x7Fu;
@@ -360,8 +395,8 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
 // ANYHIT (shadow rays, CRT_RENDER_SHADOWS): a lane stops at the first triangle that passes -- inside the leaf, and
 // for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
 // first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
-template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader, bool ANYHIT = false>
-__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, crt_lds_u32_ptr stack, LaneCounters& lc,
+template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader, bool ANYHIT = false, class Stack = CrtStack>
+__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, const Stack& stack, LaneCounters& lc,
                                                const PairLoader& loadPair = PairLoader())
 {
     Closest c;

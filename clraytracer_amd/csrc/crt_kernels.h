@@ -156,12 +156,14 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
 // after the first hit a shadow ray (new ray origin, -lightDir) decides `shadow` in `energy *= specular`. Traced only
 // where it is observable: at bounce 0 (the energy after bounce 1 is never read) and when n.l > 0 (otherwise the
 // product is 0 whatever the shadow factor).
-template <bool COUNT, bool STAMP = false, bool SHADOW = false>
-__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
-                                                              unsigned long long* __restrict__ counters)
+// WIDE: the 6-waves/SIMD flavour (25 LDS stack slots + overflow area, crt_device.h) used for frames in flight.
+template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool WIDE = false>
+__global__ __launch_bounds__(CRT_BLOCK, WIDE ? CRT_WAVES_PER_SIMD_WIDE : CRT_WAVES_PER_SIMD)
+void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
-    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    typedef CrtStackT<WIDE ? CRT_LDS_SLOTS_WIDE : CRT_STACK_DEPTH> Stack;
+    __shared__ uint32_t s_stack[Stack::kLdsSlots * CRT_BLOCK];
+    const Stack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
     if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
         ps.energy = 1.0f;
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT, STAMP>(S, ps.o, ps.d, stack, lc);
+            Closest c = closest_hit<COUNT, STAMP, GlobalPairLoader, false, Stack>(S, ps.o, ps.d, stack, lc);
             float ndl = 0.0f;
             bool cont = shade_bounce<SHADOW>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_trace_kerne
                 float shadow = 1.0f;
                 if (bounce == 0 && ndl > 0.0f) {
                     if (COUNT) { lc.rays++; lc.shadowRays++; }
-                    const Closest sc = closest_hit<COUNT, false, GlobalPairLoader, true>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc);
+                    const Closest sc = closest_hit<COUNT, false, GlobalPairLoader, true, Stack>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc);
                     if (sc.anyHit) { shadow = 0.0f; if (COUNT) lc.shadowHits++; }
                 }
                 ps.energy = ps.energy * specular_x(ndl, shadow);
@@ -226,8 +228,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_ker
                                                                 unsigned long long* __restrict__ counters,
                                                                 CrtBounceRay* __restrict__ queue, uint32_t* __restrict__ queueCount)
 {
-    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
-    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     int px, py;
     const bool active = lane_pixel(F, px, py);
@@ -265,8 +267,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kern
                                                                unsigned long long* __restrict__ counters,
                                                                const CrtBounceRay* __restrict__ queue, const uint32_t* __restrict__ queueCount)
 {
-    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
-    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     const uint32_t n = *queueCount;
     const uint32_t k = blockIdx.x * CRT_BLOCK + threadIdx.x;
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[CRT_EXP_STACK_SLOTS * CRT_BLOCK];
-    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;
     if (k < n) {

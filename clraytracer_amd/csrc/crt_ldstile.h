@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64 * CRT_LDS_WAVES) void crt_trace_lds_kernel(CrtDe
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stacks + wave * (CRT_STACK_DEPTH * 64) + lane;   // slot s of this lane at stack[s * 64]
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stacks + wave * (CRT_STACK_DEPTH * 64) + lane, S.stackOverflow };   // slot s of this lane at lds[s * 64]
     LdsPairLoader loadPair; loadPair.hot = (crt_lds_cfloat_ptr)(const float*)&s_hot[0].x;
     LaneCounters lc; zero_counters(lc);
     const int lx = (int)((lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4));

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(CRT_BLOCK, 4) void crt_trace_persistent_kernel(CrtD
                                                                            CrtQueues* __restrict__ queues)
 {
     __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
-    crt_lds_u32_ptr stack = (crt_lds_u32_ptr)s_stack + threadIdx.x;
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     const uint32_t lane = threadIdx.x;
     LaneCounters lc; zero_counters(lc);
     // DIAG builds: lane 0 keeps {service passes, lanes served, inner trips, inner lanes, leaf trips, leaf lanes, enter trips, enter lanes}

@@ -51,7 +51,7 @@ struct State {
     CrtTri* rawTris = nullptr; CrtBVHNode* rawNodes = nullptr; uint32_t* roots = nullptr; uint8_t* rawTexels = nullptr;
     // CDNA4 layouts
     float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
-    uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr;
+    uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr; uint32_t* stackOverflow = nullptr;
     CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
     float4* instBounds = nullptr; CrtDevInstance* devInstances = nullptr; uint32_t* hotSlot = nullptr;
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
@@ -124,7 +124,7 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
 
 void fill_scene(CrtDevScene& S, uint32_t numInstances)
 {
-    S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs;
+    S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs; S.stackOverflow = g.stackOverflow;
     S.instances = g.instances; S.devInstances = g.devInstances; S.instBounds = g.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
     S.numTexels = (int)((g.texelBytesHigh + 2) / 3);
     if (S.numTexels < 1) S.numTexels = 1;
@@ -341,6 +341,7 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.triCold, g.triCap * 2 * sizeof(uint4)));
     HIPCHK(hipMalloc(&g.bigLeaf, g.triCap * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.rootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.stackOverflow, CRT_OVF_WORDS * sizeof(uint32_t)));   // 224 MiB, never touched unless a stack passes 25 entries
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
     HIPCHK(hipMalloc(&g.instBounds, CRT_MAX_INSTANCES * sizeof(float4)));
@@ -383,7 +384,7 @@ int crt_shutdown(void)
     (void)sync_all();
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
-                     g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext };
+                     g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
     for (FrameSlot& fs : g.slot) { void* q[] = { fs.out, fs.order, fs.len, fs.cost }; for (void* p : q) if (p) (void)hipFree(p); }
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.statStart) (void)hipEventDestroy(g.statStart);
@@ -610,13 +611,17 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
             crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
         }
-    } else if (flags & CRT_RENDER_SHADOWS) {
-        if (count) crt_trace_kernel<true, false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
-        else crt_trace_kernel<false, false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
-    } else if (count) {
-        crt_trace_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
     } else {
-        crt_trace_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters);
+        // default megakernel: <COUNT, STAMP, SHADOW, WIDE>. WIDE (6 waves/SIMD) serves frames submitted with
+        // CRT_RENDER_ASYNC -- throughput decides there; a synchronous frame is decided by its slowest wave and
+        // runs faster on the 5-waves/SIMD flavour.
+        const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, wide = (flags & CRT_RENDER_ASYNC) != 0;
+#define CRT_LAUNCH_TRACE(C_, S_, W_) crt_trace_kernel<C_, false, S_, W_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters)
+        if (count) { if (shadow) { if (wide) CRT_LAUNCH_TRACE(true, true, true); else CRT_LAUNCH_TRACE(true, true, false); }
+                     else        { if (wide) CRT_LAUNCH_TRACE(true, false, true); else CRT_LAUNCH_TRACE(true, false, false); } }
+        else       { if (shadow) { if (wide) CRT_LAUNCH_TRACE(false, true, true); else CRT_LAUNCH_TRACE(false, true, false); }
+                     else        { if (wide) CRT_LAUNCH_TRACE(false, false, true); else CRT_LAUNCH_TRACE(false, false, false); } }
+#undef CRT_LAUNCH_TRACE
     }
     HIPCHK(hipGetLastError());
     return CRT_OK;

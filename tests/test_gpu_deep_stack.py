@@ -60,7 +60,7 @@ def caterpillar(levels, reverse=False):
 def test_hand_built_deep_tree_matches_oracle(levels, reverse, nthreads):
     sc = scenes.get("tiny")
     hip = _lib.hip()
-    W, H = 96, 64
+    W, H = (640, 368) if levels == 48 else (96, 64)      # 48 levels: thousands of waves deep in the overflow slots at once
     with driver.Session(W, H, device=0) as s:
         s.load_scene(sc)                                     # materials, textures, skybox
         a = dict(s.arenas())
@@ -82,7 +82,7 @@ def test_hand_built_deep_tree_matches_oracle(levels, reverse, nthreads):
         args.time, args.numMeshes, args.sunAngle = 0.0, 1, float(sc.sun_angle)
         fp = C.POINTER(C.c_float)
         ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle)
-        for flags in (8, 0, 4, 4, 8 | 32):
+        for flags in (8, 0, 4, 4, 8 | 4, 8 | 32, 8 | 4 | 32):   # 4 = ASYNC: the 6-waves/SIMD flavour with the overflow slots
             assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), flags) == 0
             if flags & 32:
                 ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle, shadows=True)
