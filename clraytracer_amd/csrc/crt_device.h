@@ -39,7 +39,9 @@
 #ifndef CRT_WAVES_PER_SIMD
 #define CRT_WAVES_PER_SIMD 5   // 20 waves per CU is what 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
 #endif
-#define CRT_WAVES_PER_SIMD_WIDE 6   // the flavour for frames in flight: 6400-B LDS stacks, 80 VGPRs (CrtStackT below)
+#ifndef CRT_WAVES_PER_SIMD_WIDE
+#define CRT_WAVES_PER_SIMD_WIDE 6   // the flavour for frames in flight: 6400-B LDS stacks, 80 VGPRs (CrtStackT below); 7 is slower (spills)
+#endif
 // Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126), slot indices wrapping modulo 32 where
 // upstream's array would overflow. Two flavours (template parameter LDS_SLOTS of CrtStackT):
 //  * 32: every slot in LDS -- slot s of lane l at lds[s * 64 + l], so a wave's ds_read/ds_write_b32 is conflict-free;
@@ -53,7 +55,9 @@
 //    throughput decides: +6 % there, -9 % on a synchronous frame (a few spills in the hot loop).
 // (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load.)
 typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
+#ifndef CRT_LDS_SLOTS_WIDE
 #define CRT_LDS_SLOTS_WIDE 25                      // LDS slots of the 6-waves/SIMD flavour
+#endif
 #define CRT_OVF_SLOTS (CRT_STACK_DEPTH - CRT_LDS_SLOTS_WIDE)
 #define CRT_OVF_WAVE_BITS 17                       // wave slot 4 | SIMD 2 | CU+SH 5 | SE 3 | XCC 3
 #define CRT_OVF_WORDS (((size_t)1 << CRT_OVF_WAVE_BITS) * CRT_OVF_SLOTS * 64)
@@ -85,7 +89,9 @@ struct CrtStackT {
 };
 typedef CrtStackT<CRT_STACK_DEPTH> CrtStack;       // every slot in LDS
 #define CRT_MAX_SPLIT 96   // per XCD and frame: heaviest tiles traced as four 4x4-pixel waves instead of one 8x8 wave
-#define CRT_MAX_SPLIT_PIPELINED 4  // with frames in flight the tail is hidden by the next frame: split only the very heaviest
+#ifndef CRT_MAX_SPLIT_PIPELINED
+#define CRT_MAX_SPLIT_PIPELINED 4   // with frames in flight the tail is hidden by the next frame: split only the very heaviest
+#endif
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 
 struct CrtDevScene {
