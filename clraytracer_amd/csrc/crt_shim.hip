@@ -59,6 +59,7 @@ struct State {
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
+    int forceWide = -1;   // CRT_WIDE=0/1: force the megakernel flavour (tests); default: chosen per frame
     int feedback = 1; int maxSplit = CRT_MAX_SPLIT, maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED;
     int ldsTiles = 0; uint32_t* listNext = nullptr;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
@@ -358,6 +359,7 @@ int crt_init(int device, int width, int height)
     { const char* e = getenv("CRT_SPLIT");               // tuning knob: cap on quadrant-split tiles per XCD (both modes)
       if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
       else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
+    { const char* e = getenv("CRT_WIDE"); g.forceWide = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
@@ -613,9 +615,13 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         }
     } else {
         // default megakernel: <COUNT, STAMP, SHADOW, WIDE>. WIDE (6 waves/SIMD) serves frames submitted with
-        // CRT_RENDER_ASYNC -- throughput decides there; a synchronous frame is decided by its slowest wave and
-        // runs faster on the 5-waves/SIMD flavour.
-        const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, wide = (flags & CRT_RENDER_ASYNC) != 0;
+        // CRT_RENDER_ASYNC that fill the machine at least four times over -- throughput decides there. A synchronous
+        // frame, or a small share of a frame (8 ranks at 3840x2160: 2.6 rounds of waves), is decided by its slowest
+        // waves and runs faster on the 5-waves/SIMD flavour (measured: 37.8 vs 41 Gray/s predicted for 8 ranks).
+        const size_t tiles = (size_t)F.ownedTileRows * (size_t)F.tilesX;
+        const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0;
+        const bool wide = g.forceWide >= 0 ? g.forceWide != 0
+                                           : ((flags & CRT_RENDER_ASYNC) != 0 && tiles >= (size_t)4 * (size_t)g.numCUs * 4 * CRT_WAVES_PER_SIMD_WIDE);
 #define CRT_LAUNCH_TRACE(C_, S_, W_) crt_trace_kernel<C_, false, S_, W_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters)
         if (count) { if (shadow) { if (wide) CRT_LAUNCH_TRACE(true, true, true); else CRT_LAUNCH_TRACE(true, true, false); }
                      else        { if (wide) CRT_LAUNCH_TRACE(true, false, true); else CRT_LAUNCH_TRACE(true, false, false); } }

@@ -43,6 +43,19 @@ def test_full_frame_1080p(full):
     assert st["stackOverflows"] == 0
     s.render_raw(0)
     assert np.array_equal(bits(s.read_output()), bits(gpu))
+    # frames in flight at the full size: 32400 tiles -> the 6-waves/SIMD flavour, two frame slots, split cap 4
+    for _ in range(5):
+        s.render_raw(4)
+    assert np.array_equal(bits(s.read_output()), bits(gpu))
+    s.render_raw(4 | 8)
+    assert s.counters() == st and np.array_equal(bits(s.read_output()), bits(gpu))
+    # shadow-ray extension at the full size (oracle definition: orc_trace_ex)
+    ref_s, st_s = orc.trace(rays, pos, sc.sun_angle, shadows=True)
+    s.render_raw(32 | 8)
+    assert s.counters() == st_s and np.array_equal(bits(s.read_output()), bits(ref_s))
+    s.render_raw(32 | 4); s.render_raw(32 | 4)
+    assert np.array_equal(bits(s.read_output()), bits(ref_s))
+    print(f"{sc.name} shadows: {st_s['shadowRays']} shadow rays, {st_s['shadowHits']} occluded")
 
 
 def test_hit_records_65536_rays(full):

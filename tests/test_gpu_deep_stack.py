@@ -56,8 +56,15 @@ def caterpillar(levels, reverse=False):
     return tris, nodes
 
 
+@pytest.fixture(params=["0", "1"], ids=["lds32", "lds25+overflow"])
+def flavour(request, monkeypatch):
+    """CRT_WIDE (read by crt_init) forces the megakernel flavour, which is otherwise chosen per frame by its size."""
+    monkeypatch.setenv("CRT_WIDE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("levels,reverse", [(20, False), (31, False), (34, False), (48, False), (48, True), (300, False)])
-def test_hand_built_deep_tree_matches_oracle(levels, reverse, nthreads):
+def test_hand_built_deep_tree_matches_oracle(levels, reverse, flavour, nthreads):
     sc = scenes.get("tiny")
     hip = _lib.hip()
     W, H = (640, 368) if levels == 48 else (96, 64)      # 48 levels: thousands of waves deep in the overflow slots at once
@@ -82,7 +89,7 @@ def test_hand_built_deep_tree_matches_oracle(levels, reverse, nthreads):
         args.time, args.numMeshes, args.sunAngle = 0.0, 1, float(sc.sun_angle)
         fp = C.POINTER(C.c_float)
         ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle)
-        for flags in (8, 0, 4, 4, 8 | 4, 8 | 32, 8 | 4 | 32):   # 4 = ASYNC: the 6-waves/SIMD flavour with the overflow slots
+        for flags in (8, 0, 4, 4, 8 | 32):
             assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), flags) == 0
             if flags & 32:
                 ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle, shadows=True)
