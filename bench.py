@@ -98,6 +98,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON); anything native libraries print to fd 1 on the way (RCCL's banner)
+    # goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,6 +132,9 @@ def main():
     if n > 1 or os.environ.get("CRT_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise the RCCL control plane with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                  # CRT_BENCH_FORCE_DIST without a launcher
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         if rehearse:
             dist.init_process_group(backend="gloo")
         else:
@@ -265,7 +274,7 @@ def main():
             out["cpu_baseline"] = {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                                    "sample": f"one full {width}x{height} frame of the same scene ({st['rays']} rays, {dt:.2f} s wall)",
                                    "rays_match_gpu": bool(st["rays"] == cnt["rays"])}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     s.close()
     if dist is not None:
