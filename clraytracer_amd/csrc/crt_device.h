@@ -66,7 +66,10 @@ __device__ __forceinline__ uint32_t* crt_overflow_slot(uint32_t* base, int k)
     const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]
     const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID[3:0]
     const uint32_t w = (hw & 0xFu) | (((hw >> 4) & 0x3u) << 4) | (((hw >> 8) & 0x1Fu) << 6) | (((hw >> 13) & 0x7u) << 11) | ((xcc & 0x7u) << 14);
-    return base + ((size_t)w * CRT_OVF_SLOTS + (size_t)k) * 64 + (threadIdx.x & 63);
+    uint32_t lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));      // keep the address arithmetic inside this (never taken) branch: hoisted out of the
+                                        // traversal loop it cost two VGPRs, spilled and reloaded at every push and pop
+    return base + ((size_t)w * CRT_OVF_SLOTS + (size_t)k) * 64 + lane;
 }
 template <int LDS_SLOTS>
 struct CrtStackT {
