@@ -409,7 +409,7 @@ int crt_resize(int width, int height)
 int crt_set_row_bands(int bandRows, int rank, int nRanks)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    if (bandRows < 16 || bandRows % 16 != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
+    if (bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
     RCCHK(sync_all());
     g.bandRows = bandRows; g.rank = rank; g.nRanks = nRanks;
     return CRT_OK;
@@ -417,7 +417,7 @@ int crt_set_row_bands(int bandRows, int rank, int nRanks)
 
 int crt_row_owner(int row, int bandRows, int nRanks)
 {
-    if (row < 0 || bandRows < 16 || bandRows % 16 != 0 || nRanks < 1) return CRT_E_BAD_ARGUMENT;
+    if (row < 0 || bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1) return CRT_E_BAD_ARGUMENT;
     return (row / bandRows) % nRanks;
 }
 

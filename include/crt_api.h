@@ -64,7 +64,7 @@ int crt_shutdown(void);
 /* Renderer.cpp:198-211: ignores sizes below 16 like the reference (returns CRT_OK, no change). */
 int crt_resize(int width, int height);
 /* Multi-GPU image tiling (no reference counterpart: upstream is single-device). The frame is cut
- * into horizontal bands of `bandRows` rows (multiple of 16); this process renders bands
+ * into horizontal bands of `bandRows` rows (a multiple of 8, the tile height); this process renders bands
  * rank, rank+nRanks, ... RayGen and Vignette still use full-frame coordinates. Default (16,0,1). */
 int crt_set_row_bands(int bandRows, int rank, int nRanks);
 /* Which rank renders frame row `row` under that tiling (pure function, needs no device). */

@@ -115,7 +115,7 @@ def test_upload_errors_are_codes_not_crashes():
         assert hip.crt_upload_texture_table(buf.ctypes.data, 33) == -3
         assert hip.crt_upload_instances(None, 0, 1) == -2
         assert hip.crt_upload_bvh_roots(buf.ctypes.data, 127, 2) == -3
-        assert hip.crt_set_row_bands(8, 0, 1) == -2 and hip.crt_set_row_bands(16, 2, 2) == -2
+        assert hip.crt_set_row_bands(12, 0, 1) == -2 and hip.crt_set_row_bands(16, 2, 2) == -2
         assert hip.crt_read_output(buf.ctypes.data, 5) == -2
         bad = np.full(2, 0xFFFF, np.uint16)
         inst = np.zeros(1, _lib.INSTANCE_DTYPE); inst["meshIndex"] = 500
