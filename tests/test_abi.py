@@ -61,7 +61,7 @@ def test_row_owner_is_a_partition():
             owners = [hip.crt_row_owner(y, band, n) for y in range(2160)]
             assert set(owners) == set(range(n))
             assert all(owners[y] == (y // band) % n for y in range(2160))
-    assert hip.crt_row_owner(0, 8, 2) < 0 and hip.crt_row_owner(-1, 16, 2) < 0
+    assert hip.crt_row_owner(0, 12, 2) < 0 and hip.crt_row_owner(-1, 16, 2) < 0 and hip.crt_row_owner(9, 8, 2) == 1
 
 
 def test_render_in_host_only_session_is_an_error():
