@@ -69,6 +69,10 @@ HIP_API = {
     "crt_upload_texture_table": (C.c_int, [_vp, _sz]),
     "crt_upload_texels": (C.c_int, [_vp, _sz, _sz]),
     "crt_upload_instances": (C.c_int, [_vp, _sz, _sz]),
+    "crt_build_bvh": (C.c_int, [_sz, _vp, C.c_int, _sz, _sz, C.POINTER(C.c_uint32)]),
+    "crt_download_triangles": (C.c_int, [_vp, _sz, _sz]),
+    "crt_download_bvh_nodes": (C.c_int, [_vp, _sz, _sz]),
+    "crt_download_bvh_roots": (C.c_int, [_vp, _sz, _sz]),
     "crt_render": (C.c_int, [C.POINTER(CrtTraceArgs), _fp, _fp, C.c_int]),
     "crt_sync": (C.c_int, []),
     "crt_query_hits": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp]),

@@ -1,0 +1,377 @@
+// crt_bvh_build.h -- BuildBVH (BVH.cpp:218-255) on the device: the reference's 8-bin SAH builder, level by level,
+// producing the SAME bytes the sequential host builder produces -- triangle order, node numbering, bounds.
+//
+// Why that is possible although upstream is a depth-first recursion over an in-place partition:
+//  * bounds, centroid ranges, bin counts and bin boxes are min/max/integer reductions -> order-free. (Where a sequential
+//    `a < b ? a : b` fold can return either sign of zero, only *stored* node bounds are affected; they are fixed up
+//    below by looking at the last zero in sequence order.)
+//  * the 21-plane sweep of one node is 21 dependent steps -> one thread replays it literally.
+//  * the partition loop `while (i <= j) { if (c[i] < split) i++; else swap(t[i], t[j--]); }` (BVH.cpp:185-192) has a
+//    closed form. Examine order: elements come from the front while they are left-class (a right-class one ends the
+//    front phase), then from the back while they are right-class (a left-class one ends the back phase), and so on;
+//    left-class elements fill positions 0,1,.. and right-class ones n-1,n-2,.. in examine order. With L = number of
+//    left-class elements, holes r_1<r_2<.. = right-class positions below L, and l_1<l_2<.. = back-order indices
+//    (y = n-1-x) of the left-class elements at or above L, that gives
+//        front left  x            -> x                      back left  #m  -> r_m
+//        front right #m (also the right-class element AT L, as #G+1)       -> back slot l_{m-1}+1  (l_0 = -1)
+//        back  right y            -> back slot y+1          (array position x-1)
+//    which two prefix sums and two small tables evaluate in parallel. It also covers the degenerate partitions
+//    (L == 0 or L == n) after which upstream keeps the node a leaf but leaves its triangles permuted.
+//  * nodes are numbered by the recursion (children = next two free indices, then the whole left subtree, then the
+//    right one): once the tree is known, index(left) = base, index(right) = base+1, base(left) = base+2,
+//    base(right) = base+2+descendants(left), top-down from each mesh's root.
+// Triangles move between two buffers, one level per pass; a finished leaf's segment is written to both.
+#pragma once
+#include "crt_device.h"
+
+#define CRT_BVH_BINS 8
+#define CRT_BVH_NONE 0xFFFFFFFFu
+
+struct CrtBuildNode {
+    uint32_t first, count;           // triangle range (absolute indices into the triangle pool)
+    uint32_t left, right;            // build-node ids of the children, CRT_BVH_NONE for a leaf
+    float bmin[3], bmax[3];          // UpdateNodeBounds
+    float splitPos; int axis;
+    uint32_t state;                  // 0 = undecided, 1 = split, 2 = leaf, 3 = leaf whose triangles the failed partition permuted
+    uint32_t desc;                   // number of descendant nodes
+    uint32_t index, base;            // final node index; first free index when this node was subdivided
+    uint32_t pad;
+};
+
+__device__ __forceinline__ const float* bvh_tri_f(const CrtTri* t, size_t i) { return reinterpret_cast<const float*>(t + i); }
+__device__ __forceinline__ float bvh_centroid(const CrtTri* t, size_t i, int axis) { return bvh_tri_f(t, i)[3 + 4 * axis]; }
+__device__ __forceinline__ uint32_t bvh_ordered(float f) { const uint32_t b = __float_as_uint(f); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ float bvh_unordered(uint32_t o) { return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+// BVH.cpp:41-46 + hsum_ps_sse3 (SIMDCommon.hpp:183-189): (e0*e0 + e1*e0) + (e2*e2 + 0)
+__device__ __forceinline__ float bvh_area(const float* mn, const float* mx)
+{
+    const float e0 = mx[0] - mn[0], e1 = mx[1] - mn[1], e2 = mx[2] - mn[2];
+    return (e0 * e0 + e1 * e0) + (e2 * e2 + 0.0f);
+}
+
+// BVH.cpp:232-234
+__global__ void crt_bvh_centroids(CrtTri* __restrict__ tris, size_t first, size_t count)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    float* t = reinterpret_cast<float*>(tris + first + k);
+    t[3] = ((t[0] + t[4]) + t[8]) * 0.333333f;
+    t[7] = ((t[1] + t[5]) + t[9]) * 0.333333f;
+    t[11] = ((t[2] + t[6]) + t[10]) * 0.333333f;
+}
+
+__global__ void crt_bvh_init_roots(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ meshTriCounts, int numMeshes, uint32_t firstTri)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t cur = firstTri;
+    for (int m = 0; m < numMeshes; ++m) {
+        CrtBuildNode n;
+        n.first = cur; n.count = meshTriCounts[m]; n.left = n.right = CRT_BVH_NONE;
+        for (int c = 0; c < 3; ++c) { n.bmin[c] = 1e30f; n.bmax[c] = -1e30f; }
+        n.splitPos = 0.0f; n.axis = 0; n.state = 0; n.desc = 0; n.index = 0; n.base = 0; n.pad = 0;
+        nodes[m] = n;
+        cur += meshTriCounts[m];
+    }
+}
+
+// Nodes of one level are handled by one workgroup each; two launch shapes share every kernel: 64-thread groups take the
+// nodes with at most CRT_BVH_SMALL triangles, 1024-thread groups the others.
+#define CRT_BVH_SMALL 2048
+__device__ __forceinline__ bool bvh_my_node(const CrtBuildNode& n) { return (blockDim.x <= 64) == (n.count <= CRT_BVH_SMALL); }
+
+// UpdateNodeBounds (BVH.cpp:54-74) for the nodes [begin, begin + gridDim.x).
+__global__ void crt_bvh_bounds(CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ tris)
+{
+    CrtBuildNode& node = nodes[begin + blockIdx.x];
+    if (!bvh_my_node(node)) return;
+    __shared__ uint32_t s_min[3], s_max[3];
+    __shared__ int s_last[6];
+    const uint32_t first = node.first, n = node.count;
+    if (threadIdx.x < 3) { s_min[threadIdx.x] = bvh_ordered(1e30f); s_max[threadIdx.x] = bvh_ordered(-1e30f); }
+    if (threadIdx.x < 6) s_last[threadIdx.x] = -1;
+    __syncthreads();
+    float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float* t = bvh_tri_f(tris, (size_t)first + i);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float x = t[4 * v + c]; mn[c] = mn[c] < x ? mn[c] : x; mx[c] = mx[c] > x ? mx[c] : x; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { atomicMin(&s_min[c], bvh_ordered(mn[c])); atomicMax(&s_max[c], bvh_ordered(mx[c])); }
+    __syncthreads();
+    float rmin[3], rmax[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rmin[c] = bvh_unordered(s_min[c]); rmax[c] = bvh_unordered(s_max[c]); }
+    // sign of a zero bound: the sequential fold `acc < x ? acc : x` keeps the LAST zero it meets (tris in order, v0 v1 v2)
+    bool anyZero = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) anyZero = anyZero || rmin[c] == 0.0f || rmax[c] == 0.0f;
+    if (anyZero) {
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const float* t = bvh_tri_f(tris, (size_t)first + i);
+            for (int v = 0; v < 3; ++v)
+                for (int c = 0; c < 3; ++c)
+                    if (t[4 * v + c] == 0.0f) {
+                        if (rmin[c] == 0.0f) atomicMax(&s_last[c], (int)(i * 3 + v));
+                        if (rmax[c] == 0.0f) atomicMax(&s_last[3 + c], (int)(i * 3 + v));
+                    }
+        }
+        __syncthreads();
+        for (int c = 0; c < 3; ++c) {
+            if (rmin[c] == 0.0f && s_last[c] >= 0) rmin[c] = bvh_tri_f(tris, (size_t)first + s_last[c] / 3)[4 * (s_last[c] % 3) + c];
+            if (rmax[c] == 0.0f && s_last[3 + c] >= 0) rmax[c] = bvh_tri_f(tris, (size_t)first + s_last[3 + c] / 3)[4 * (s_last[3 + c] % 3) + c];
+        }
+    }
+    if (threadIdx.x == 0)
+        for (int c = 0; c < 3; ++c) { node.bmin[c] = rmin[c]; node.bmax[c] = rmax[c]; }
+}
+
+// FindBestSplitPlane + the split decision (BVH.cpp:103-163, 169-177) for the nodes [begin, begin + gridDim.x).
+__global__ void crt_bvh_split(CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ tris)
+{
+    CrtBuildNode& node = nodes[begin + blockIdx.x];
+    if (!bvh_my_node(node)) return;
+    __shared__ uint32_t s_cmin[3], s_cmax[3];
+    __shared__ uint32_t s_cnt[3][CRT_BVH_BINS];
+    __shared__ uint32_t s_bmin[3][CRT_BVH_BINS][3], s_bmax[3][CRT_BVH_BINS][3];
+    const uint32_t first = node.first, n = node.count;
+    for (int k = threadIdx.x; k < 3 * CRT_BVH_BINS; k += blockDim.x) {
+        const int a = k / CRT_BVH_BINS, b = k % CRT_BVH_BINS;
+        s_cnt[a][b] = 0;
+        for (int c = 0; c < 3; ++c) { s_bmin[a][b][c] = bvh_ordered(1e30f); s_bmax[a][b][c] = bvh_ordered(-1e30f); }
+    }
+    if (threadIdx.x < 3) { s_cmin[threadIdx.x] = bvh_ordered(1e30f); s_cmax[threadIdx.x] = bvh_ordered(-1e30f); }
+    __syncthreads();
+    {
+        float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float v = bvh_centroid(tris, (size_t)first + i, a); mn[a] = mn[a] < v ? mn[a] : v; mx[a] = mx[a] > v ? mx[a] : v; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&s_cmin[a], bvh_ordered(mn[a])); atomicMax(&s_cmax[a], bvh_ordered(mx[a])); }
+    }
+    __syncthreads();
+    float cmin[3], cmax[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { cmin[a] = bvh_unordered(s_cmin[a]); cmax[a] = bvh_unordered(s_cmax[a]); }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float* t = bvh_tri_f(tris, (size_t)first + i);
+        float tmn[3], tmx[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float lo = 1e30f, hi = -1e30f;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; lo = lo < x ? lo : x; hi = hi > x ? hi : x; }
+            tmn[c] = lo; tmx[c] = hi;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (cmax[a] == cmin[a]) continue;
+            const float scale = (float)CRT_BVH_BINS / (cmax[a] - cmin[a]);
+            int b = f2i((t[3 + 4 * a] - cmin[a]) * scale);
+            b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
+            if (b < 0) b = 0;
+            atomicAdd(&s_cnt[a][b], 1u);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { atomicMin(&s_bmin[a][b][c], bvh_ordered(tmn[c])); atomicMax(&s_bmax[a][b][c], bvh_ordered(tmx[c])); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    // the sweep, literally (BVH.cpp:131-160)
+    float bestCost = 1e30f, splitPos = 0.0f; int bestAxis = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (cmax[a] == cmin[a]) continue;
+        float leftArea[CRT_BVH_BINS - 1], rightArea[CRT_BVH_BINS - 1];
+        int leftCount[CRT_BVH_BINS - 1], rightCount[CRT_BVH_BINS - 1];
+        int leftSum = 0, rightSum = 0;
+        float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
+        float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
+        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
+            leftSum += (int)s_cnt[a][i];
+            leftCount[i] = leftSum;
+            {   // aabb::grow(aabb) (BVH.cpp:29-37): skipped for an empty box
+                float bmn[3], bmx[3];
+                for (int c = 0; c < 3; ++c) { bmn[c] = bvh_unordered(s_bmin[a][i][c]); bmx[c] = bvh_unordered(s_bmax[a][i][c]); }
+                if (bmn[0] != 1e30f)
+                    for (int c = 0; c < 3; ++c) {
+                        lmn[c] = lmn[c] < bmn[c] ? lmn[c] : bmn[c]; lmx[c] = lmx[c] > bmn[c] ? lmx[c] : bmn[c];
+                        lmn[c] = lmn[c] < bmx[c] ? lmn[c] : bmx[c]; lmx[c] = lmx[c] > bmx[c] ? lmx[c] : bmx[c];
+                    }
+            }
+            leftArea[i] = bvh_area(lmn, lmx);
+            const int rb = CRT_BVH_BINS - 1 - i;
+            rightSum += (int)s_cnt[a][rb];
+            rightCount[CRT_BVH_BINS - 2 - i] = rightSum;
+            {
+                float bmn[3], bmx[3];
+                for (int c = 0; c < 3; ++c) { bmn[c] = bvh_unordered(s_bmin[a][rb][c]); bmx[c] = bvh_unordered(s_bmax[a][rb][c]); }
+                if (bmn[0] != 1e30f)
+                    for (int c = 0; c < 3; ++c) {
+                        rmn[c] = rmn[c] < bmn[c] ? rmn[c] : bmn[c]; rmx[c] = rmx[c] > bmn[c] ? rmx[c] : bmn[c];
+                        rmn[c] = rmn[c] < bmx[c] ? rmn[c] : bmx[c]; rmx[c] = rmx[c] > bmx[c] ? rmx[c] : bmx[c];
+                    }
+            }
+            rightArea[CRT_BVH_BINS - 2 - i] = bvh_area(rmn, rmx);
+        }
+        const float scale = (cmax[a] - cmin[a]) / (float)CRT_BVH_BINS;
+        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
+            const float planeCost = (float)leftCount[i] * leftArea[i] + (float)rightCount[i] * rightArea[i];
+            if (planeCost < bestCost) { splitPos = cmin[a] + scale * (float)(i + 1); bestAxis = a; bestCost = planeCost; }
+        }
+    }
+    const float nosplitCost = (float)n * bvh_area(node.bmin, node.bmax);
+    node.axis = bestAxis; node.splitPos = splitPos;
+    node.state = (bestCost >= nosplitCost) ? 2u : 1u;
+}
+
+// block-wide exclusive scan of one flag per thread; returns this thread's rank and the block total
+__device__ __forceinline__ uint32_t bvh_block_scan(uint32_t flag, uint32_t* s_wave, uint32_t& total)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const unsigned long long m = __ballot(flag != 0);
+    const uint32_t inWave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < nw; ++w) { const uint32_t c = s_wave[w]; if (w < wave) base += c; tot += c; }
+    __syncthreads();
+    total = tot;
+    return base + inWave;
+}
+
+__device__ __forceinline__ void bvh_copy_tri(CrtTri* __restrict__ dst, size_t d, const CrtTri* __restrict__ src, size_t s)
+{
+    const uint4* a = reinterpret_cast<const uint4*>(src + s);
+    uint4* b = reinterpret_cast<uint4*>(dst + d);
+    const uint4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4];
+    b[0] = q0; b[1] = q1; b[2] = q2; b[3] = q3; b[4] = q4;
+}
+
+// The partition (BVH.cpp:185-195) of the nodes [begin, begin + gridDim.x): src -> dst in the closed form above, children
+// appended to the node array. `rank`, `holes`, `backL` are per-triangle scratch arrays indexed like the triangle pool.
+__global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
+                                  uint32_t poolFirst, uint32_t* __restrict__ rank, uint32_t* __restrict__ holes, uint32_t* __restrict__ backL,
+                                  uint32_t* __restrict__ nodeCounter /* [0] next node id, [1] largest child */)
+{
+    CrtBuildNode& node = nodes[begin + blockIdx.x];
+    if (!bvh_my_node(node)) return;
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_L;
+    const uint32_t first = node.first, n = node.count;
+    if (node.state != 1u) {                                   // leaf by the cost test: same order in both buffers
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) bvh_copy_tri(dst, (size_t)first + i, src, (size_t)first + i);
+        return;
+    }
+    const int axis = node.axis; const float splitPos = node.splitPos;
+    uint32_t* rk = rank + (first - poolFirst); uint32_t* hl = holes + (first - poolFirst); uint32_t* bl = backL + (first - poolFirst);
+    if (threadIdx.x == 0) s_L = 0;
+    __syncthreads();
+    {
+        uint32_t c = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) c += bvh_centroid(src, (size_t)first + i, axis) < splitPos ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_L, c);
+    }
+    __syncthreads();
+    const uint32_t L = s_L;
+    // front region [0, L): rank of every right-class element among the holes, holes[m] = x
+    uint32_t G = 0;
+    for (uint32_t base = 0; base < L; base += blockDim.x) {
+        const uint32_t x = base + threadIdx.x;
+        const bool isR = x < L && !(bvh_centroid(src, (size_t)first + x, axis) < splitPos);
+        uint32_t tot; const uint32_t r = bvh_block_scan(isR ? 1u : 0u, s_wave, tot);
+        if (isR) { rk[x] = G + r; hl[G + r] = x; }
+        G += tot;
+    }
+    // back region in back order y = n-1-x, x >= L: rank of every left-class element, backL[m] = y
+    uint32_t GB = 0;
+    const uint32_t nb = n - L;
+    for (uint32_t base = 0; base < nb; base += blockDim.x) {
+        const uint32_t y = base + threadIdx.x;
+        const bool isL = y < nb && (bvh_centroid(src, (size_t)first + (n - 1 - y), axis) < splitPos);
+        uint32_t tot; const uint32_t r = bvh_block_scan(isL ? 1u : 0u, s_wave, tot);
+        if (isL) { rk[n - 1 - y] = GB + r; bl[GB + r] = y; }
+        GB += tot;
+    }
+    __syncthreads();                                          // tables complete (G == GB by counting)
+    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) {
+        const bool isLeft = bvh_centroid(src, (size_t)first + x, axis) < splitPos;
+        uint32_t dest;
+        if (x < L) {
+            if (isLeft) dest = x;
+            else { const uint32_t m = rk[x]; const uint32_t slot = m == 0 ? 0u : bl[m - 1] + 1u; dest = n - 1 - slot; }
+        } else if (isLeft) dest = hl[rk[x]];
+        else if (x == L) { const uint32_t slot = G == 0 ? 0u : bl[G - 1] + 1u; dest = n - 1 - slot; }
+        else dest = x - 1;
+        bvh_copy_tri(dst, (size_t)first + dest, src, (size_t)first + x);
+    }
+    if (threadIdx.x == 0) {
+        if (L == 0 || L == n) node.state = 3u;                 // BVH.cpp:194: stays a leaf, triangles stay permuted
+        else {
+            const uint32_t id = atomicAdd(nodeCounter, 2u);
+            atomicMax(nodeCounter + 1, L > n - L ? L : n - L);          // largest child of the level: picks the launch shapes
+            node.left = id; node.right = id + 1;
+            CrtBuildNode c;
+            c.left = c.right = CRT_BVH_NONE; c.splitPos = 0.0f; c.axis = 0; c.state = 0; c.desc = 0; c.index = 0; c.base = 0; c.pad = 0;
+            for (int k = 0; k < 3; ++k) { c.bmin[k] = 1e30f; c.bmax[k] = -1e30f; }
+            c.first = first; c.count = L; nodes[id] = c;
+            c.first = first + L; c.count = n - L; nodes[id + 1] = c;
+        }
+    }
+}
+
+// A node that stopped being subdivided at this level must hold the same triangle order in both buffers.
+__global__ void crt_bvh_sync_leaf(const CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ from, CrtTri* __restrict__ to)
+{
+    const CrtBuildNode& node = nodes[begin + blockIdx.x];
+    if (!bvh_my_node(node) || node.state != 3u) return;
+    for (uint32_t i = threadIdx.x; i < node.count; i += blockDim.x) bvh_copy_tri(to, (size_t)node.first + i, from, (size_t)node.first + i);
+}
+
+// descendants, bottom-up: one launch per level, deepest first
+__global__ void crt_bvh_count_desc(CrtBuildNode* __restrict__ nodes, uint32_t begin, uint32_t count)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    CrtBuildNode& n = nodes[begin + k];
+    n.desc = n.left == CRT_BVH_NONE ? 0u : 2u + nodes[n.left].desc + nodes[n.right].desc;
+}
+
+// roots are numbered mesh after mesh: BVH.cpp:238-251 (root = next free index, then its whole subtree)
+__global__ void crt_bvh_number_roots(CrtBuildNode* __restrict__ nodes, int numMeshes, uint32_t firstNode, uint32_t* __restrict__ roots, uint32_t* __restrict__ nodesUsed)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t cur = firstNode;
+    for (int m = 0; m < numMeshes; ++m) {
+        nodes[m].index = cur; nodes[m].base = cur + 1; roots[m] = cur;
+        cur += 1u + nodes[m].desc;
+    }
+    *nodesUsed = cur - firstNode;
+}
+
+// top-down, one launch per level: SubdivideBVH's allocation order (BVH.cpp:203-215)
+__global__ void crt_bvh_number_children(CrtBuildNode* __restrict__ nodes, uint32_t begin, uint32_t count)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const CrtBuildNode& n = nodes[begin + k];
+    if (n.left == CRT_BVH_NONE) return;
+    CrtBuildNode& l = nodes[n.left]; CrtBuildNode& r = nodes[n.right];
+    l.index = n.base; r.index = n.base + 1;
+    l.base = n.base + 2; r.base = n.base + 2 + l.desc;
+}
+
+__global__ void crt_bvh_emit(const CrtBuildNode* __restrict__ nodes, uint32_t count, CrtBVHNode* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const CrtBuildNode& n = nodes[k];
+    CrtBVHNode o;
+    for (int c = 0; c < 3; ++c) { o.aabbMin[c] = n.bmin[c]; o.aabbMax[c] = n.bmax[c]; }
+    if (n.left == CRT_BVH_NONE) { o.leftFirst = n.first; o.triCount = n.count; }
+    else { o.leftFirst = nodes[n.left].index; o.triCount = 0; }
+    out[n.index] = o;
+}

@@ -12,6 +12,9 @@
 #include "../../include/crt_api.h"
 #include "crt_kernels.h"
 #include "crt_relayout.h"
+#include "crt_bvh_build.h"
+#include <vector>
+#include <utility>
 
 // ------------------------------------------------------------------------------------------------
 // host state
@@ -64,6 +67,7 @@ struct State {
     int ldsTiles = 0; uint32_t* listNext = nullptr;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
+    void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
     uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
     bool sceneValid = true;
@@ -386,7 +390,7 @@ int crt_shutdown(void)
     (void)sync_all();
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
-                     g.queryBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
+                     g.queryBuf, g.buildBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
     for (FrameSlot& fs : g.slot) { void* q[] = { fs.out, fs.order, fs.len, fs.cost }; for (void* p : q) if (p) (void)hipFree(p); }
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.statStart) (void)hipEventDestroy(g.statStart);
@@ -530,6 +534,139 @@ int crt_upload_instances(const void* instances, size_t first, size_t count)
     memcpy(g.hInstances + first, instances, count * sizeof(CrtMeshInstance));
     if (first + count > g.instHigh) g.instHigh = (uint32_t)(first + count);
     return rebuild_instance_bounds();
+}
+
+// BuildBVH on the device (crt_bvh_build.h): same triangle order, node numbering and bounds as the host builder.
+int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes, size_t firstNode, size_t firstMesh, uint32_t* nodesUsedOut)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!meshTriCounts || numMeshes < 1) return CRT_E_BAD_ARGUMENT;
+    if (firstMesh + (size_t)numMeshes > CRT_MAX_MESHES) return CRT_E_OUT_OF_RANGE;
+    size_t total = 0;
+    for (int m = 0; m < numMeshes; ++m) { if (meshTriCounts[m] == 0) return CRT_E_BAD_ARGUMENT; total += meshTriCounts[m]; }
+    if (firstTri + total > g.trisHigh) return CRT_E_BAD_ARGUMENT;                  // triangles must have been uploaded
+    if (firstTri + total > 0x00FFFFFFu) return CRT_E_OUT_OF_RANGE;                 // leaf references carry 24-bit triangle indices
+    if (firstNode + 2 * total > g.nodeCap) return CRT_E_OUT_OF_RANGE;              // a mesh of n triangles needs at most 2n-1 nodes
+    RCCHK(sync_all());
+
+    // scratch: second triangle buffer | build nodes | rank, holes, backL | mesh counts, roots | node counter, max child, nodes used
+    const size_t maxNodes = 2 * total + (size_t)numMeshes;
+    const size_t offNodes = (total * sizeof(CrtTri) + 255) & ~(size_t)255;
+    const size_t offRank = (offNodes + maxNodes * sizeof(CrtBuildNode) + 255) & ~(size_t)255;
+    const size_t offSmall = (offRank + 3 * total * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t need = offSmall + (2 * (size_t)numMeshes + 4) * sizeof(uint32_t);
+    if (need > g.buildBytes) {
+        if (g.buildBuf) (void)hipFree(g.buildBuf);
+        g.buildBuf = nullptr; g.buildBytes = 0;
+        HIPCHK(hipMalloc(&g.buildBuf, need));
+        g.buildBytes = need;
+    }
+    char* base = static_cast<char*>(g.buildBuf);
+    CrtTri* A = g.rawTris;
+    CrtTri* B = reinterpret_cast<CrtTri*>(base) - firstTri;                        // indexed with absolute triangle indices, like A
+    CrtBuildNode* bn = reinterpret_cast<CrtBuildNode*>(base + offNodes);
+    uint32_t* rank = reinterpret_cast<uint32_t*>(base + offRank);
+    uint32_t* holes = rank + total; uint32_t* backL = holes + total;
+    uint32_t* dCounts = reinterpret_cast<uint32_t*>(base + offSmall);
+    uint32_t* dRoots = dCounts + numMeshes;
+    uint32_t* dScalars = dRoots + numMeshes;                                       // [0] node counter, [1] largest child, [2] nodes used
+    hipStream_t st = g.stream;
+    HIPCHK(hipMemcpyAsync(dCounts, meshTriCounts, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    uint32_t hs[3] = { (uint32_t)numMeshes, 0u, 0u };
+    uint32_t largest = 0;
+    for (int m = 0; m < numMeshes; ++m) largest = meshTriCounts[m] > largest ? meshTriCounts[m] : largest;
+    HIPCHK(hipMemcpyAsync(dScalars, hs, sizeof hs, hipMemcpyHostToDevice, st));
+    crt_bvh_centroids<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(A, firstTri, total);
+    crt_bvh_init_roots<<<1, 1, 0, st>>>(bn, dCounts, numMeshes, (uint32_t)firstTri);
+    HIPCHK(hipGetLastError());
+
+    // each kernel runs in two shapes: 64 threads for the nodes with <= CRT_BVH_SMALL triangles, 1024 for the rest
+    #define CRT_BVH_BOTH(kernel, nblocks, ...) do { \
+        kernel<<<(nblocks), 64, 0, st>>>(__VA_ARGS__); \
+        if (largest > CRT_BVH_SMALL) kernel<<<(nblocks), 1024, 0, st>>>(__VA_ARGS__); } while (0)
+    CRT_BVH_BOTH(crt_bvh_bounds, (unsigned)numMeshes, bn, 0u, A);
+    std::vector<std::pair<uint32_t, uint32_t>> levels;
+    uint32_t begin = 0, end = (uint32_t)numMeshes;
+    CrtTri* src = A; CrtTri* dst = B;
+    while (end > begin) {
+        const unsigned n = end - begin;
+        levels.push_back(std::make_pair(begin, end));
+        CRT_BVH_BOTH(crt_bvh_split, n, bn, begin, src);
+        HIPCHK(hipMemsetAsync(dScalars + 1, 0, sizeof(uint32_t), st));
+        CRT_BVH_BOTH(crt_bvh_partition, n, bn, begin, src, dst, (uint32_t)firstTri, rank, holes, backL, dScalars);
+        CRT_BVH_BOTH(crt_bvh_sync_leaf, n, bn, begin, dst, src);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hs, dScalars, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const uint32_t newEnd = hs[0];
+        if (newEnd > (uint32_t)maxNodes) return CRT_E_OUT_OF_RANGE;
+        largest = hs[1];
+        if (newEnd > end) CRT_BVH_BOTH(crt_bvh_bounds, newEnd - end, bn, end, dst);
+        begin = end; end = newEnd;
+        CrtTri* t = src; src = dst; dst = t;
+    }
+    #undef CRT_BVH_BOTH
+    const uint32_t numBuilt = end;
+    for (size_t l = levels.size(); l-- > 0;) {
+        const uint32_t c = levels[l].second - levels[l].first;
+        crt_bvh_count_desc<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
+    }
+    crt_bvh_number_roots<<<1, 1, 0, st>>>(bn, numMeshes, (uint32_t)firstNode, dRoots, dScalars + 2);
+    for (size_t l = 0; l < levels.size(); ++l) {
+        const uint32_t c = levels[l].second - levels[l].first;
+        crt_bvh_number_children<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
+    }
+    HIPCHK(hipGetLastError());
+    uint32_t used = 0;
+    HIPCHK(hipMemcpyAsync(&used, dScalars + 2, sizeof used, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (used != numBuilt || firstNode + used > g.nodeCap) return CRT_E_OUT_OF_RANGE;
+    crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, g.rawNodes);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g.roots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(g.hRoots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    crt_relayout_tris<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.rawTris, firstTri, total, g.triHot, g.triCold);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if (firstNode + used > g.nodeCount) g.nodeCount = (uint32_t)(firstNode + used);
+    if (firstMesh + (size_t)numMeshes > g.numRoots) g.numRoots = (uint32_t)(firstMesh + (size_t)numMeshes);
+    if (nodesUsedOut) *nodesUsedOut = used;
+    return rebuild_bvh_layout();
+}
+
+// Read back the reference-layout pools (after crt_build_bvh: the reordered triangles with their centroids, the nodes,
+// the roots), e.g. to keep host arenas in step with the device.
+int crt_download_triangles(void* dst, size_t byteOffset, size_t bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (bytes == 0) return CRT_OK;
+    if (!dst || byteOffset % sizeof(CrtTri) || bytes % sizeof(CrtTri)) return CRT_E_BAD_ARGUMENT;
+    if (byteOffset + bytes > g.triCap * sizeof(CrtTri)) return CRT_E_OUT_OF_RANGE;
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, reinterpret_cast<const char*>(g.rawTris) + byteOffset, bytes, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_download_bvh_nodes(void* dst, size_t byteOffset, size_t bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (bytes == 0) return CRT_OK;
+    if (!dst || byteOffset % sizeof(CrtBVHNode) || bytes % sizeof(CrtBVHNode)) return CRT_E_BAD_ARGUMENT;
+    if (byteOffset + bytes > g.nodeCap * sizeof(CrtBVHNode)) return CRT_E_OUT_OF_RANGE;
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, reinterpret_cast<const char*>(g.rawNodes) + byteOffset, bytes, hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (count == 0) return CRT_OK;
+    if (!dst) return CRT_E_BAD_ARGUMENT;
+    if (firstMesh + count > CRT_MAX_MESHES) return CRT_E_OUT_OF_RANGE;
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, g.roots + firstMesh, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CRT_OK;
 }
 
 // Feedback launch lists for the megakernel (lane_pixel / crt_order_kernel). Buffers follow the frame geometry; a

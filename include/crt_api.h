@@ -85,6 +85,17 @@ int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes);
 /* Renderer.cpp:245,314 */
 int crt_upload_instances(const void* instances, size_t first, size_t count);
 
+/* BuildBVH (BVH.cpp:218-255; called from ResourceManager.cpp:282) on the device, for triangles already uploaded with
+ * crt_upload_triangles: `numMeshes` meshes of meshTriCounts[m] triangles each, stored back to back from triangle
+ * `firstTri`. Writes the triangle centroids, reorders the triangles, writes the nodes from node index `firstNode` and
+ * the roots of meshes firstMesh.. -- byte for byte what the host BuildBVH produces for the same input (triangle
+ * order, node numbering by the recursion's allocation order, bounds) -- and re-lays everything out for rendering.
+ * *nodesUsedOut = number of nodes written. The crt_download_* calls read the reference-layout pools back. */
+int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes, size_t firstNode, size_t firstMesh, uint32_t* nodesUsedOut);
+int crt_download_triangles(void* dst, size_t byteOffset, size_t bytes);
+int crt_download_bvh_nodes(void* dst, size_t byteOffset, size_t bytes);
+int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count);
+
 /* Renderer.cpp:337-367: RayGen + Trace (+ PostProcess) for one frame, then (unless ASYNC) wait.
  * invView / invProj are the camera's inverse matrices, row-major (hazard H10: taken as inputs).
  * Frames in flight (no reference counterpart): consecutive CRT_RENDER_ASYNC frames alternate between two frame
