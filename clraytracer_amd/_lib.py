@@ -99,6 +99,7 @@ HOST_API = {
     "crth_import_texture_rgb8": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp]),
     "crth_import_mesh": (C.c_int, [C.c_char_p]),
     "crth_push_meshes": (None, []),
+    "crth_set_device_bvh_build": (None, [C.c_int]),
     "crth_push_textures": (None, []),
     "crth_push_materials": (None, []),
     "crth_create_material": (C.c_int, [C.c_int]),

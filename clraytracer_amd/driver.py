@@ -44,8 +44,9 @@ class Session:
             raise CrtError(f"{what}: error {rc}: {self.hip.crt_error_string(rc).decode()}")
 
     # ---- scene ----
-    def load_scene(self, scene):
+    def load_scene(self, scene, device_bvh_build=False):
         h = self.h
+        h.crth_set_device_bvh_build(1 if device_bvh_build else 0)   # BuildBVH on the GPU (same bytes as the host build)
         h.crth_prepare_meshes()
         tex = h.crth_import_texture(scene.skybox.encode())   # must be texture index 2 (Engine.cpp:60-61)
         self._check("ImportTexture(skybox)")

@@ -163,6 +163,7 @@ uint build_one(Tri* tris, uint firstTri, uint triCount, BVHNode* nodes, uint bas
 } // namespace
 
 void ResetBVHNodeCounter() { g_totalNodesUsed = 0; g_overflowed = false; }
+void AdvanceBVHNodeCounter(uint nodes) { g_totalNodesUsed += nodes; }
 void SetBVHNodeCapacity(size_t nodes) { g_nodeCapacity = nodes; }
 bool BVHBuildOverflowed() { return g_overflowed; }
 

@@ -50,6 +50,7 @@ namespace {
     uint numberOfBVH = 0;
     int numTextures = 0, numMeshes = 0, numMaterials = 0;
     bool deviceOn = true;
+    bool deviceBuild = false;
     bool initialized = false;
     int lastError = 0;
 
@@ -233,9 +234,33 @@ MeshHandle ResourceManager::ImportMesh(const char* path) // ResourceManager.cpp:
     return (MeshHandle)numMeshes++;
 }
 
+void ResourceManager::SetDeviceBVHBuild(bool enabled) { deviceBuild = enabled; }
+
 void ResourceManager::PushMeshesToGPU() // ResourceManager.cpp:280-300
 {
     if (numMeshes == (int)numberOfBVH) return;
+    if (deviceOn && deviceBuild) {
+        // upload the triangles as imported, build on the device, read the reordered triangles / nodes / roots back so the
+        // host arenas (CPU_RayCast, tools) hold exactly what the device renders from
+        const int newMeshes = numMeshes - (int)numberOfBVH;
+        uint counts[MaxMeshes];
+        for (int m = 0; m < newMeshes; ++m) counts[m] = meshInfos[numberOfBVH + m].numTriangles;
+        const size_t addedTriangleSize = (numTriangles - lastTriangleCount) * sizeof(Tri);
+        uint numNodesUsed = 0;
+        int rc = crt_upload_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
+        if (rc == 0) rc = crt_build_bvh(lastTriangleCount, counts, newMeshes, lastBVHIndex, numberOfBVH, &numNodesUsed);
+        if (rc == 0) rc = crt_download_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
+        if (rc == 0) rc = crt_download_bvh_nodes(g_BVHNodes + lastBVHIndex, lastBVHIndex * sizeof(BVHNode), sizeof(BVHNode) * numNodesUsed);
+        if (rc == 0) rc = crt_download_bvh_roots(g_BVHIndices + numberOfBVH, numberOfBVH, (size_t)newMeshes);
+        note(rc, "crt_build_bvh");
+        if (rc != 0) return;
+        note(crt_upload_materials(g_Materials, 0, (size_t)numMaterials), "crt_upload_materials");
+        AdvanceBVHNodeCounter(numNodesUsed);
+        numberOfBVH = (uint)numMeshes;
+        lastBVHIndex += numNodesUsed;
+        lastTriangleCount = numTriangles;
+        return;
+    }
     const uint numNodesUsed = BuildBVH(g_Triangles + lastTriangleCount, meshInfos + numberOfBVH, numMeshes - (int)numberOfBVH,
                                        g_BVHNodes, g_BVHIndices + numberOfBVH);
     if (BVHBuildOverflowed()) {

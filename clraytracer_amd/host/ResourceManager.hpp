@@ -53,6 +53,9 @@ namespace ResourceManager
     // deviceUploads=false keeps everything on the host (importer / BVH / CPU_RayCast only);
     // any attempt to render then fails loudly.
     void Initialize(bool deviceUploads = true);
+    // BuildBVH on the device (crt_build_bvh: same bytes as the host builder) instead of on the host; the host arenas are
+    // then filled from the device. Off by default, like upstream (ResourceManager.cpp:282 builds on the CPU).
+    void SetDeviceBVHBuild(bool enabled);
     void Destroy();
     void Finalize();
 
@@ -71,4 +74,5 @@ extern uint* g_BVHIndices;
 uint BuildBVH(Tri* tris, MeshInfo* meshes, int numMeshes, BVHNode* nodes, uint* bvhIndices);
 void SetBVHNodeCapacity(size_t nodes); // 0 = unchecked
 bool BVHBuildOverflowed();
+void AdvanceBVHNodeCounter(uint nodes); // nodes written by a builder other than BuildBVH (crt_build_bvh)
 void ResetBVHNodeCounter(); // the reference's file-static totalNodesUsed (BVH.cpp:49) is never reset; Finalize() does

@@ -37,6 +37,7 @@ int crth_import_texture(const char* path) { return ResourceManager::ImportTextur
 int crth_import_texture_rgb8(const char* name, int w, int h, const unsigned char* rgb) { return ResourceManager::ImportTextureRGB8(name, w, h, rgb); }
 int crth_import_mesh(const char* path) { return ResourceManager::ImportMesh(path); }
 void crth_push_meshes(void) { ResourceManager::PushMeshesToGPU(); }
+void crth_set_device_bvh_build(int enabled) { ResourceManager::SetDeviceBVHBuild(enabled != 0); }
 void crth_push_textures(void) { ResourceManager::PushTexturesToGPU(); }
 void crth_push_materials(void) { ResourceManager::PushMaterialsToGPU(); }
 int crth_create_material(int count) { MaterialHandle h = 0; return ResourceManager::CreateMaterial(&h, count) ? (int)h : -1; }

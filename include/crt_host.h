@@ -25,6 +25,7 @@ int crth_import_texture(const char* path);                   /* ResourceManager:
 int crth_import_texture_rgb8(const char* name, int width, int height, const unsigned char* rgb);
 int crth_import_mesh(const char* path);                      /* ResourceManager::ImportMesh */
 void crth_push_meshes(void);                                 /* ResourceManager::PushMeshesToGPU */
+void crth_set_device_bvh_build(int enabled);                 /* ResourceManager::SetDeviceBVHBuild */
 void crth_push_textures(void);                               /* ResourceManager::PushTexturesToGPU */
 void crth_push_materials(void);                              /* ResourceManager::PushMaterialsToGPU */
 int crth_create_material(int count);                         /* ResourceManager::CreateMaterial -> first handle, -1 on failure */

@@ -136,3 +136,23 @@ def test_scene_built_on_device_renders_identically(name, nthreads):
         want, st = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
         s.render_raw(8)
         assert np.array_equal(bits(s.read_output()), bits(want)) and s.counters() == st
+
+
+@pytest.mark.parametrize("name", ["tiny", "sponza-class-250k", "multi-1M"])
+def test_mirrored_resource_manager_with_device_build(name):
+    """ResourceManager::SetDeviceBVHBuild(true): PushMeshesToGPU builds on the device and fills the host arenas from
+    it; arenas and frames equal those of the host build."""
+    sc = scenes.get(name)
+    with driver.Session(256, 144, device=0) as s:
+        t0 = time.perf_counter(); s.load_scene(sc); t_host = time.perf_counter() - t0
+        s.render_raw(0)
+        ref = s.read_output()
+        a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in s.arenas().items()}
+    with driver.Session(256, 144, device=0) as s:
+        t0 = time.perf_counter(); s.load_scene(sc, device_bvh_build=True); t_dev = time.perf_counter() - t0
+        b = s.arenas()
+        for k in ("tris", "nodes", "roots", "instances"):
+            assert a[k].tobytes() == b[k].tobytes(), k
+        s.render_raw(0)
+        assert np.array_equal(bits(s.read_output()), bits(ref))
+        print(f"{name}: load_scene {t_host * 1e3:.0f} ms with the host BuildBVH, {t_dev * 1e3:.0f} ms with crt_build_bvh")
