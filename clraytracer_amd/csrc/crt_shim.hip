@@ -68,6 +68,7 @@ struct State {
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
+    CrtTri* buildTris = nullptr;                               // crt_build_bvh: second triangle pool (same indexing as rawTris)
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
     uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
     bool sceneValid = true;
@@ -390,7 +391,7 @@ int crt_shutdown(void)
     (void)sync_all();
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
-                     g.queryBuf, g.buildBuf, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
+                     g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
     for (FrameSlot& fs : g.slot) { void* q[] = { fs.out, fs.order, fs.len, fs.cost }; for (void* p : q) if (p) (void)hipFree(p); }
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.statStart) (void)hipEventDestroy(g.statStart);
@@ -549,9 +550,11 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     if (firstNode + 2 * total > g.nodeCap) return CRT_E_OUT_OF_RANGE;              // a mesh of n triangles needs at most 2n-1 nodes
     RCCHK(sync_all());
 
-    // scratch: second triangle buffer | build nodes | rank, holes, backL | mesh counts, roots | node counter, max child, nodes used
+    // second triangle pool (allocated on first use, indexed like rawTris) and scratch:
+    // build nodes | rank, holes, backL | mesh counts, roots | node counter, max child, nodes used
+    if (!g.buildTris) HIPCHK(hipMalloc(&g.buildTris, g.triCap * sizeof(CrtTri)));
     const size_t maxNodes = 2 * total + (size_t)numMeshes;
-    const size_t offNodes = (total * sizeof(CrtTri) + 255) & ~(size_t)255;
+    const size_t offNodes = 0;
     const size_t offRank = (offNodes + maxNodes * sizeof(CrtBuildNode) + 255) & ~(size_t)255;
     const size_t offSmall = (offRank + 3 * total * sizeof(uint32_t) + 255) & ~(size_t)255;
     const size_t need = offSmall + (2 * (size_t)numMeshes + 4) * sizeof(uint32_t);
@@ -563,7 +566,7 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     }
     char* base = static_cast<char*>(g.buildBuf);
     CrtTri* A = g.rawTris;
-    CrtTri* B = reinterpret_cast<CrtTri*>(base) - firstTri;                        // indexed with absolute triangle indices, like A
+    CrtTri* B = g.buildTris;
     CrtBuildNode* bn = reinterpret_cast<CrtBuildNode*>(base + offNodes);
     uint32_t* rank = reinterpret_cast<uint32_t*>(base + offRank);
     uint32_t* holes = rank + total; uint32_t* backL = holes + total;
