@@ -74,16 +74,35 @@ __global__ void crt_bvh_init_roots(CrtBuildNode* __restrict__ nodes, const uint3
     }
 }
 
-// Nodes of one level are handled by one workgroup each; two launch shapes share every kernel: 64-thread groups take the
-// nodes with at most CRT_BVH_SMALL triangles, 1024-thread groups the others.
+// The nodes of one level are kept in three compact id lists by size: BIG (> CRT_BVH_SMALL triangles) and MID nodes get
+// one workgroup each (1024 / 64 threads) running the parallel formulation; TINY nodes (<= CRT_BVH_TINY triangles -- the
+// bulk of the deep levels: the builder splits down to one or two triangles per leaf) get one THREAD each that replays
+// upstream's sequential code literally (crt_bvh_tiny).
 #define CRT_BVH_SMALL 2048
-__device__ __forceinline__ bool bvh_my_node(const CrtBuildNode& n) { return (blockDim.x <= 64) == (n.count <= CRT_BVH_SMALL); }
-
-// UpdateNodeBounds (BVH.cpp:54-74) for the nodes [begin, begin + gridDim.x).
-__global__ void crt_bvh_bounds(CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ tris)
+#define CRT_BVH_TINY 8
+enum { CRT_BVH_CLASS_BIG = 0, CRT_BVH_CLASS_MID = 1, CRT_BVH_CLASS_TINY = 2 };
+__host__ __device__ __forceinline__ int bvh_class(uint32_t count) { return count > CRT_BVH_SMALL ? CRT_BVH_CLASS_BIG : (count > CRT_BVH_TINY ? CRT_BVH_CLASS_MID : CRT_BVH_CLASS_TINY); }
+// scalars shared with the host: [0] next free build-node id, [1..3] entries in next level's BIG / MID / TINY list, [4] nodes used
+struct CrtBuildLists { uint32_t* list[3]; };   // next level's id lists (device pointers)
+__device__ __forceinline__ void bvh_new_children(CrtBuildNode* nodes, CrtBuildNode& node, uint32_t first, uint32_t L, uint32_t n,
+                                                 uint32_t* scal, const CrtBuildLists& next)
 {
-    CrtBuildNode& node = nodes[begin + blockIdx.x];
-    if (!bvh_my_node(node)) return;
+    const uint32_t id = atomicAdd(&scal[0], 2u);
+    node.left = id; node.right = id + 1;
+    CrtBuildNode c;
+    c.left = c.right = CRT_BVH_NONE; c.splitPos = 0.0f; c.axis = 0; c.state = 0; c.desc = 0; c.index = 0; c.base = 0; c.pad = 0;
+    for (int k = 0; k < 3; ++k) { c.bmin[k] = 1e30f; c.bmax[k] = -1e30f; }
+    c.first = first; c.count = L; nodes[id] = c;
+    c.first = first + L; c.count = n - L; nodes[id + 1] = c;
+    const int cl = bvh_class(L), cr = bvh_class(n - L);
+    next.list[cl][atomicAdd(&scal[1 + cl], 1u)] = id;
+    next.list[cr][atomicAdd(&scal[1 + cr], 1u)] = id + 1;
+}
+
+// UpdateNodeBounds (BVH.cpp:54-74) for the nodes list[0 .. gridDim.x).
+__global__ void crt_bvh_bounds(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtTri* __restrict__ tris)
+{
+    CrtBuildNode& node = nodes[list[blockIdx.x]];
     __shared__ uint32_t s_min[3], s_max[3];
     __shared__ int s_last[6];
     const uint32_t first = node.first, n = node.count;
@@ -128,11 +147,10 @@ __global__ void crt_bvh_bounds(CrtBuildNode* __restrict__ nodes, uint32_t begin,
         for (int c = 0; c < 3; ++c) { node.bmin[c] = rmin[c]; node.bmax[c] = rmax[c]; }
 }
 
-// FindBestSplitPlane + the split decision (BVH.cpp:103-163, 169-177) for the nodes [begin, begin + gridDim.x).
-__global__ void crt_bvh_split(CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ tris)
+// FindBestSplitPlane + the split decision (BVH.cpp:103-163, 169-177) for the nodes list[0 .. gridDim.x).
+__global__ void crt_bvh_split(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtTri* __restrict__ tris)
 {
-    CrtBuildNode& node = nodes[begin + blockIdx.x];
-    if (!bvh_my_node(node)) return;
+    CrtBuildNode& node = nodes[list[blockIdx.x]];
     __shared__ uint32_t s_cmin[3], s_cmax[3];
     __shared__ uint32_t s_cnt[3][CRT_BVH_BINS];
     __shared__ uint32_t s_bmin[3][CRT_BVH_BINS][3], s_bmax[3][CRT_BVH_BINS][3];
@@ -250,14 +268,14 @@ __device__ __forceinline__ void bvh_copy_tri(CrtTri* __restrict__ dst, size_t d,
     b[0] = q0; b[1] = q1; b[2] = q2; b[3] = q3; b[4] = q4;
 }
 
-// The partition (BVH.cpp:185-195) of the nodes [begin, begin + gridDim.x): src -> dst in the closed form above, children
-// appended to the node array. `rank`, `holes`, `backL` are per-triangle scratch arrays indexed like the triangle pool.
-__global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
+// The partition (BVH.cpp:185-195) of the nodes list[0 .. gridDim.x): src -> dst in the closed form above, children appended
+// to the node array and to next level's lists. `rank`, `holes`, `backL` are per-triangle scratch arrays indexed like the
+// triangle pool. A node that stops here ends with the same triangle order in both buffers.
+__global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
                                   uint32_t poolFirst, uint32_t* __restrict__ rank, uint32_t* __restrict__ holes, uint32_t* __restrict__ backL,
-                                  uint32_t* __restrict__ nodeCounter /* [0] next node id, [1] largest child */)
+                                  uint32_t* __restrict__ scal, CrtBuildLists next)
 {
-    CrtBuildNode& node = nodes[begin + blockIdx.x];
-    if (!bvh_my_node(node)) return;
+    CrtBuildNode& node = nodes[list[blockIdx.x]];
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_L;
     const uint32_t first = node.first, n = node.count;
@@ -308,27 +326,108 @@ __global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, uint32_t beg
         else dest = x - 1;
         bvh_copy_tri(dst, (size_t)first + dest, src, (size_t)first + x);
     }
-    if (threadIdx.x == 0) {
-        if (L == 0 || L == n) node.state = 3u;                 // BVH.cpp:194: stays a leaf, triangles stay permuted
-        else {
-            const uint32_t id = atomicAdd(nodeCounter, 2u);
-            atomicMax(nodeCounter + 1, L > n - L ? L : n - L);          // largest child of the level: picks the launch shapes
-            node.left = id; node.right = id + 1;
-            CrtBuildNode c;
-            c.left = c.right = CRT_BVH_NONE; c.splitPos = 0.0f; c.axis = 0; c.state = 0; c.desc = 0; c.index = 0; c.base = 0; c.pad = 0;
-            for (int k = 0; k < 3; ++k) { c.bmin[k] = 1e30f; c.bmax[k] = -1e30f; }
-            c.first = first; c.count = L; nodes[id] = c;
-            c.first = first + L; c.count = n - L; nodes[id + 1] = c;
-        }
-    }
+    if (L == 0 || L == n) {                                   // BVH.cpp:194: stays a leaf, triangles stay permuted -> both buffers
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) bvh_copy_tri(src, (size_t)first + i, dst, (size_t)first + i);
+        if (threadIdx.x == 0) node.state = 3u;
+    } else if (threadIdx.x == 0) bvh_new_children(nodes, node, first, L, n, scal, next);
 }
 
-// A node that stopped being subdivided at this level must hold the same triangle order in both buffers.
-__global__ void crt_bvh_sync_leaf(const CrtBuildNode* __restrict__ nodes, uint32_t begin, const CrtTri* __restrict__ from, CrtTri* __restrict__ to)
+// UpdateNodeBounds for TINY nodes: one thread per node, the sequential fold itself.
+__global__ void crt_bvh_bounds_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, const CrtTri* __restrict__ tris)
 {
-    const CrtBuildNode& node = nodes[begin + blockIdx.x];
-    if (!bvh_my_node(node) || node.state != 3u) return;
-    for (uint32_t i = threadIdx.x; i < node.count; i += blockDim.x) bvh_copy_tri(to, (size_t)node.first + i, from, (size_t)node.first + i);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    CrtBuildNode& node = nodes[list[k]];
+    float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+    for (uint32_t i = 0; i < node.count; ++i) {
+        const float* t = bvh_tri_f(tris, (size_t)node.first + i);
+        for (int c = 0; c < 3; ++c)
+            for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; mn[c] = mn[c] < x ? mn[c] : x; mx[c] = mx[c] > x ? mx[c] : x; }
+    }
+    for (int c = 0; c < 3; ++c) { node.bmin[c] = mn[c]; node.bmax[c] = mx[c]; }
+}
+
+// One level of SubdivideBVH (BVH.cpp:165-216) for TINY nodes, one thread per node: FindBestSplitPlane, the cost test, the
+// partition loop and the child records exactly as upstream runs them, on at most CRT_BVH_TINY triangles.
+__global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
+                             uint32_t* __restrict__ scal, CrtBuildLists next)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    CrtBuildNode& node = nodes[list[k]];
+    const uint32_t first = node.first, n = node.count;
+    float bestCost = 1e30f, splitPos = 0.0f; int bestAxis = 0;
+    for (int a = 0; a < 3; ++a) {
+        float boundsMin = 1e30f, boundsMax = -1e30f;
+        for (uint32_t i = 0; i < n; ++i) { const float v = bvh_centroid(src, (size_t)first + i, a); boundsMin = boundsMin < v ? boundsMin : v; boundsMax = boundsMax > v ? boundsMax : v; }
+        if (boundsMax == boundsMin) continue;
+        uint32_t cnt[CRT_BVH_BINS]; float bmn[CRT_BVH_BINS][3], bmx[CRT_BVH_BINS][3];
+        for (int b = 0; b < CRT_BVH_BINS; ++b) { cnt[b] = 0; for (int c = 0; c < 3; ++c) { bmn[b][c] = 1e30f; bmx[b][c] = -1e30f; } }
+        float scale = (float)CRT_BVH_BINS / (boundsMax - boundsMin);
+        for (uint32_t i = 0; i < n; ++i) {
+            const float* t = bvh_tri_f(src, (size_t)first + i);
+            int b = f2i((t[3 + 4 * a] - boundsMin) * scale);
+            b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
+            if (b < 0) b = 0;
+            cnt[b]++;
+            for (int c = 0; c < 3; ++c)
+                for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; bmn[b][c] = bmn[b][c] < x ? bmn[b][c] : x; bmx[b][c] = bmx[b][c] > x ? bmx[b][c] : x; }
+        }
+        float leftArea[CRT_BVH_BINS - 1], rightArea[CRT_BVH_BINS - 1];
+        int leftCount[CRT_BVH_BINS - 1], rightCount[CRT_BVH_BINS - 1];
+        int leftSum = 0, rightSum = 0;
+        float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
+        float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
+        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
+            leftSum += (int)cnt[i];
+            leftCount[i] = leftSum;
+            if (bmn[i][0] != 1e30f)
+                for (int c = 0; c < 3; ++c) {
+                    lmn[c] = lmn[c] < bmn[i][c] ? lmn[c] : bmn[i][c]; lmx[c] = lmx[c] > bmn[i][c] ? lmx[c] : bmn[i][c];
+                    lmn[c] = lmn[c] < bmx[i][c] ? lmn[c] : bmx[i][c]; lmx[c] = lmx[c] > bmx[i][c] ? lmx[c] : bmx[i][c];
+                }
+            leftArea[i] = bvh_area(lmn, lmx);
+            const int rb = CRT_BVH_BINS - 1 - i;
+            rightSum += (int)cnt[rb];
+            rightCount[CRT_BVH_BINS - 2 - i] = rightSum;
+            if (bmn[rb][0] != 1e30f)
+                for (int c = 0; c < 3; ++c) {
+                    rmn[c] = rmn[c] < bmn[rb][c] ? rmn[c] : bmn[rb][c]; rmx[c] = rmx[c] > bmn[rb][c] ? rmx[c] : bmn[rb][c];
+                    rmn[c] = rmn[c] < bmx[rb][c] ? rmn[c] : bmx[rb][c]; rmx[c] = rmx[c] > bmx[rb][c] ? rmx[c] : bmx[rb][c];
+                }
+            rightArea[CRT_BVH_BINS - 2 - i] = bvh_area(rmn, rmx);
+        }
+        scale = (boundsMax - boundsMin) / (float)CRT_BVH_BINS;
+        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
+            const float planeCost = (float)leftCount[i] * leftArea[i] + (float)rightCount[i] * rightArea[i];
+            if (planeCost < bestCost) { splitPos = boundsMin + scale * (float)(i + 1); bestAxis = a; bestCost = planeCost; }
+        }
+    }
+    const float nosplitCost = (float)n * bvh_area(node.bmin, node.bmax);
+    node.axis = bestAxis; node.splitPos = splitPos;
+    if (bestCost >= nosplitCost) {                             // leaf: same order in both buffers
+        node.state = 2u;
+        for (uint32_t i = 0; i < n; ++i) bvh_copy_tri(dst, (size_t)first + i, src, (size_t)first + i);
+        return;
+    }
+    // the partition loop on an index permutation (BVH.cpp:185-192), then one copy per triangle
+    uint32_t perm[CRT_BVH_TINY];
+    for (uint32_t i = 0; i < n; ++i) perm[i] = i;
+    int i = 0, j = (int)n - 1;
+    while (i <= j) {
+        if (bvh_centroid(src, (size_t)first + perm[i], bestAxis) < splitPos) i++;
+        else { const uint32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t; j--; }
+    }
+    const uint32_t L = (uint32_t)i;
+    for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(dst, (size_t)first + x, src, (size_t)first + perm[x]);
+    if (L == 0 || L == n) {
+        node.state = 3u;
+        for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(src, (size_t)first + x, dst, (size_t)first + x);
+    } else {
+        node.state = 1u;
+        bvh_new_children(nodes, node, first, L, n, scal, next);
+    }
 }
 
 // descendants, bottom-up: one launch per level, deepest first

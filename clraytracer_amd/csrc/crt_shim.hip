@@ -551,13 +551,15 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     RCCHK(sync_all());
 
     // second triangle pool (allocated on first use, indexed like rawTris) and scratch:
-    // build nodes | rank, holes, backL | mesh counts, roots | node counter, max child, nodes used
+    // build nodes | rank, holes, backL | 2 x 3 id lists | mesh counts, roots | scalars
     if (!g.buildTris) HIPCHK(hipMalloc(&g.buildTris, g.triCap * sizeof(CrtTri)));
     const size_t maxNodes = 2 * total + (size_t)numMeshes;
     const size_t offNodes = 0;
     const size_t offRank = (offNodes + maxNodes * sizeof(CrtBuildNode) + 255) & ~(size_t)255;
-    const size_t offSmall = (offRank + 3 * total * sizeof(uint32_t) + 255) & ~(size_t)255;
-    const size_t need = offSmall + (2 * (size_t)numMeshes + 4) * sizeof(uint32_t);
+    const size_t offLists = (offRank + 3 * total * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t listCap = total + (size_t)numMeshes;                              // a level never has more nodes than triangles
+    const size_t offSmall = (offLists + 6 * listCap * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t need = offSmall + (2 * (size_t)numMeshes + 8) * sizeof(uint32_t);
     if (need > g.buildBytes) {
         if (g.buildBuf) (void)hipFree(g.buildBuf);
         g.buildBuf = nullptr; g.buildBytes = 0;
@@ -570,58 +572,73 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     CrtBuildNode* bn = reinterpret_cast<CrtBuildNode*>(base + offNodes);
     uint32_t* rank = reinterpret_cast<uint32_t*>(base + offRank);
     uint32_t* holes = rank + total; uint32_t* backL = holes + total;
+    uint32_t* listMem = reinterpret_cast<uint32_t*>(base + offLists);
+    CrtBuildLists lists[2];
+    for (int p = 0; p < 2; ++p) for (int c = 0; c < 3; ++c) lists[p].list[c] = listMem + ((size_t)p * 3 + (size_t)c) * listCap;
     uint32_t* dCounts = reinterpret_cast<uint32_t*>(base + offSmall);
     uint32_t* dRoots = dCounts + numMeshes;
-    uint32_t* dScalars = dRoots + numMeshes;                                       // [0] node counter, [1] largest child, [2] nodes used
+    uint32_t* dScal = dRoots + numMeshes;                                          // [0] next node id, [1..3] next level's list sizes, [4] nodes used
     hipStream_t st = g.stream;
     HIPCHK(hipMemcpyAsync(dCounts, meshTriCounts, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    uint32_t hs[3] = { (uint32_t)numMeshes, 0u, 0u };
-    uint32_t largest = 0;
-    for (int m = 0; m < numMeshes; ++m) largest = meshTriCounts[m] > largest ? meshTriCounts[m] : largest;
-    HIPCHK(hipMemcpyAsync(dScalars, hs, sizeof hs, hipMemcpyHostToDevice, st));
+    // level 0 = the roots, classified here
+    uint32_t cnt[3] = { 0, 0, 0 };
+    {
+        std::vector<uint32_t> ids[3];
+        for (int m = 0; m < numMeshes; ++m) ids[bvh_class(meshTriCounts[m])].push_back((uint32_t)m);
+        for (int c = 0; c < 3; ++c) {
+            cnt[c] = (uint32_t)ids[c].size();
+            if (cnt[c]) HIPCHK(hipMemcpyAsync(lists[0].list[c], ids[c].data(), cnt[c] * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));                                          // ids[] go out of scope
+    }
     crt_bvh_centroids<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(A, firstTri, total);
     crt_bvh_init_roots<<<1, 1, 0, st>>>(bn, dCounts, numMeshes, (uint32_t)firstTri);
     HIPCHK(hipGetLastError());
 
-    // each kernel runs in two shapes: 64 threads for the nodes with <= CRT_BVH_SMALL triangles, 1024 for the rest
-    #define CRT_BVH_BOTH(kernel, nblocks, ...) do { \
-        kernel<<<(nblocks), 64, 0, st>>>(__VA_ARGS__); \
-        if (largest > CRT_BVH_SMALL) kernel<<<(nblocks), 1024, 0, st>>>(__VA_ARGS__); } while (0)
-    CRT_BVH_BOTH(crt_bvh_bounds, (unsigned)numMeshes, bn, 0u, A);
+    auto bounds = [&](const CrtBuildLists& L, const uint32_t n[3], const CrtTri* tris) {
+        if (n[0]) crt_bvh_bounds<<<n[0], 1024, 0, st>>>(bn, L.list[0], tris);
+        if (n[1]) crt_bvh_bounds<<<n[1], 64, 0, st>>>(bn, L.list[1], tris);
+        if (n[2]) crt_bvh_bounds_tiny<<<(n[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], n[2], tris);
+    };
+    bounds(lists[0], cnt, A);
     std::vector<std::pair<uint32_t, uint32_t>> levels;
     uint32_t begin = 0, end = (uint32_t)numMeshes;
     CrtTri* src = A; CrtTri* dst = B;
+    int cur = 0;
     while (end > begin) {
-        const unsigned n = end - begin;
         levels.push_back(std::make_pair(begin, end));
-        CRT_BVH_BOTH(crt_bvh_split, n, bn, begin, src);
-        HIPCHK(hipMemsetAsync(dScalars + 1, 0, sizeof(uint32_t), st));
-        CRT_BVH_BOTH(crt_bvh_partition, n, bn, begin, src, dst, (uint32_t)firstTri, rank, holes, backL, dScalars);
-        CRT_BVH_BOTH(crt_bvh_sync_leaf, n, bn, begin, dst, src);
+        const CrtBuildLists& L = lists[cur]; const CrtBuildLists& N = lists[cur ^ 1];
+        uint32_t hs[4] = { end, 0u, 0u, 0u };
+        HIPCHK(hipMemcpyAsync(dScal, hs, sizeof hs, hipMemcpyHostToDevice, st));
+        if (cnt[0]) { crt_bvh_split<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src);
+                      crt_bvh_partition<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src, dst, (uint32_t)firstTri, rank, holes, backL, dScal, N); }
+        if (cnt[1]) { crt_bvh_split<<<cnt[1], 64, 0, st>>>(bn, L.list[1], src);
+                      crt_bvh_partition<<<cnt[1], 64, 0, st>>>(bn, L.list[1], src, dst, (uint32_t)firstTri, rank, holes, backL, dScal, N); }
+        if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, dScal, N);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(hs, dScalars, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hs, dScal, sizeof hs, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         const uint32_t newEnd = hs[0];
-        if (newEnd > (uint32_t)maxNodes) return CRT_E_OUT_OF_RANGE;
-        largest = hs[1];
-        if (newEnd > end) CRT_BVH_BOTH(crt_bvh_bounds, newEnd - end, bn, end, dst);
+        if (newEnd > (uint32_t)maxNodes || hs[1] + hs[2] + hs[3] != newEnd - end) return CRT_E_OUT_OF_RANGE;
+        cnt[0] = hs[1]; cnt[1] = hs[2]; cnt[2] = hs[3];
+        bounds(N, cnt, dst);
         begin = end; end = newEnd;
         CrtTri* t = src; src = dst; dst = t;
+        cur ^= 1;
     }
-    #undef CRT_BVH_BOTH
     const uint32_t numBuilt = end;
     for (size_t l = levels.size(); l-- > 0;) {
         const uint32_t c = levels[l].second - levels[l].first;
         crt_bvh_count_desc<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
     }
-    crt_bvh_number_roots<<<1, 1, 0, st>>>(bn, numMeshes, (uint32_t)firstNode, dRoots, dScalars + 2);
+    crt_bvh_number_roots<<<1, 1, 0, st>>>(bn, numMeshes, (uint32_t)firstNode, dRoots, dScal + 4);
     for (size_t l = 0; l < levels.size(); ++l) {
         const uint32_t c = levels[l].second - levels[l].first;
         crt_bvh_number_children<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
     }
     HIPCHK(hipGetLastError());
     uint32_t used = 0;
-    HIPCHK(hipMemcpyAsync(&used, dScalars + 2, sizeof used, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&used, dScal + 4, sizeof used, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (used != numBuilt || firstNode + used > g.nodeCap) return CRT_E_OUT_OF_RANGE;
     crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, g.rawNodes);
