@@ -82,12 +82,28 @@ __global__ void crt_bvh_init_roots(CrtBuildNode* __restrict__ nodes, const uint3
 #define CRT_BVH_TINY 8
 enum { CRT_BVH_CLASS_BIG = 0, CRT_BVH_CLASS_MID = 1, CRT_BVH_CLASS_TINY = 2 };
 __host__ __device__ __forceinline__ int bvh_class(uint32_t count) { return count > CRT_BVH_SMALL ? CRT_BVH_CLASS_BIG : (count > CRT_BVH_TINY ? CRT_BVH_CLASS_MID : CRT_BVH_CLASS_TINY); }
-// scalars shared with the host: [0] next free build-node id, [1..3] entries in next level's BIG / MID / TINY list, [4] nodes used
-struct CrtBuildLists { uint32_t* list[3]; };   // next level's id lists (device pointers)
-__device__ __forceinline__ void bvh_new_children(CrtBuildNode* nodes, CrtBuildNode& node, uint32_t first, uint32_t L, uint32_t n,
-                                                 uint32_t* scal, const CrtBuildLists& next)
+// Children are appended to the node array and to next level's lists with ONE 64-bit atomic per splitting node (per wave
+// in crt_bvh_tiny): the counter packs next level's three list sizes -- TINY in bits 0..23, MID in 24..43 (a MID node has
+// more than 8 triangles: < 2^20 of them per level), BIG in 44..55 (more than 2048 triangles: < 2^12) -- and because every
+// child takes exactly one list slot, the number of children created so far is the sum of the three fields, which
+// numbers the new nodes. (Three separate same-address atomics per node cost 20 of the 34 ms of a 1 M-triangle build.)
+#define CRT_BVH_PACK_TINY(x) ((unsigned long long)(x))
+#define CRT_BVH_PACK_MID(x) ((unsigned long long)(x) << 24)
+#define CRT_BVH_PACK_BIG(x) ((unsigned long long)(x) << 44)
+__host__ __device__ __forceinline__ uint32_t bvh_unpack(unsigned long long p, int cls)
 {
-    const uint32_t id = atomicAdd(&scal[0], 2u);
+    return cls == CRT_BVH_CLASS_TINY ? (uint32_t)(p & 0xFFFFFFull) : (cls == CRT_BVH_CLASS_MID ? (uint32_t)((p >> 24) & 0xFFFFFull) : (uint32_t)((p >> 44) & 0xFFFull));
+}
+__host__ __device__ __forceinline__ unsigned long long bvh_pack_one(int cls)
+{
+    return cls == CRT_BVH_CLASS_TINY ? CRT_BVH_PACK_TINY(1) : (cls == CRT_BVH_CLASS_MID ? CRT_BVH_PACK_MID(1) : CRT_BVH_PACK_BIG(1));
+}
+struct CrtBuildLists { uint32_t* list[3]; };   // next level's id lists (device pointers)
+// writes the two child records of `node`; `before` = the packed counter before this node's two children were added
+__device__ __forceinline__ void bvh_new_children(CrtBuildNode* nodes, CrtBuildNode& node, uint32_t first, uint32_t L, uint32_t n,
+                                                 uint32_t levelEnd, unsigned long long before, const CrtBuildLists& next)
+{
+    const uint32_t id = levelEnd + bvh_unpack(before, 0) + bvh_unpack(before, 1) + bvh_unpack(before, 2);
     node.left = id; node.right = id + 1;
     CrtBuildNode c;
     c.left = c.right = CRT_BVH_NONE; c.splitPos = 0.0f; c.axis = 0; c.state = 0; c.desc = 0; c.index = 0; c.base = 0; c.pad = 0;
@@ -95,8 +111,8 @@ __device__ __forceinline__ void bvh_new_children(CrtBuildNode* nodes, CrtBuildNo
     c.first = first; c.count = L; nodes[id] = c;
     c.first = first + L; c.count = n - L; nodes[id + 1] = c;
     const int cl = bvh_class(L), cr = bvh_class(n - L);
-    next.list[cl][atomicAdd(&scal[1 + cl], 1u)] = id;
-    next.list[cr][atomicAdd(&scal[1 + cr], 1u)] = id + 1;
+    next.list[cl][bvh_unpack(before, cl)] = id;
+    next.list[cr][bvh_unpack(before + bvh_pack_one(cl), cr)] = id + 1;
 }
 
 // UpdateNodeBounds (BVH.cpp:54-74) for the nodes list[0 .. gridDim.x).
@@ -273,7 +289,7 @@ __device__ __forceinline__ void bvh_copy_tri(CrtTri* __restrict__ dst, size_t d,
 // triangle pool. A node that stops here ends with the same triangle order in both buffers.
 __global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
                                   uint32_t poolFirst, uint32_t* __restrict__ rank, uint32_t* __restrict__ holes, uint32_t* __restrict__ backL,
-                                  uint32_t* __restrict__ scal, CrtBuildLists next)
+                                  uint32_t levelEnd, unsigned long long* __restrict__ packed, CrtBuildLists next)
 {
     CrtBuildNode& node = nodes[list[blockIdx.x]];
     __shared__ uint32_t s_wave[16];
@@ -330,7 +346,10 @@ __global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, const uint32
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) bvh_copy_tri(src, (size_t)first + i, dst, (size_t)first + i);
         if (threadIdx.x == 0) node.state = 3u;
-    } else if (threadIdx.x == 0) bvh_new_children(nodes, node, first, L, n, scal, next);
+    } else if (threadIdx.x == 0) {
+        const unsigned long long before = atomicAdd(packed, bvh_pack_one(bvh_class(L)) + bvh_pack_one(bvh_class(n - L)));
+        bvh_new_children(nodes, node, first, L, n, levelEnd, before, next);
+    }
 }
 
 // UpdateNodeBounds for TINY nodes: one thread per node, the sequential fold itself.
@@ -348,86 +367,115 @@ __global__ void crt_bvh_bounds_tiny(CrtBuildNode* __restrict__ nodes, const uint
     for (int c = 0; c < 3; ++c) { node.bmin[c] = mn[c]; node.bmax[c] = mx[c]; }
 }
 
-// One level of SubdivideBVH (BVH.cpp:165-216) for TINY nodes, one thread per node: FindBestSplitPlane, the cost test, the
-// partition loop and the child records exactly as upstream runs them, on at most CRT_BVH_TINY triangles.
+// One level of SubdivideBVH (BVH.cpp:165-216) for TINY nodes, one thread per node, everything in registers: the
+// triangles' boxes and centroids are loaded once (loops over the at most CRT_BVH_TINY triangles are fully unrolled so
+// the small arrays never reach scratch). Per candidate plane the left/right boxes are the min/max over the triangles
+// binned left/right of it -- the same values upstream gets by growing bin boxes and merging them in sweep order
+// (min/max are exact; an empty side keeps the (1e30, -1e30) box and its NaN cost, as upstream). The partition loop
+// runs literally on a nibble-packed index permutation.
 __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
-                             uint32_t* __restrict__ scal, CrtBuildLists next)
+                             uint32_t levelEnd, unsigned long long* __restrict__ packed, CrtBuildLists next)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
-    CrtBuildNode& node = nodes[list[k]];
-    const uint32_t first = node.first, n = node.count;
+    const bool live = k < count;
+    CrtBuildNode& node = nodes[list[live ? k : 0]];           // lanes past the end idle through the code (n = 0) so the wave stays converged
+    const uint32_t first = node.first, n = live ? node.count : 0u;
+    float tmn[CRT_BVH_TINY][3], tmx[CRT_BVH_TINY][3], cen[CRT_BVH_TINY][3];
+#pragma unroll
+    for (int i = 0; i < CRT_BVH_TINY; ++i) {
+        if ((uint32_t)i < n) {
+            const float* t = bvh_tri_f(src, (size_t)first + i);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float lo = 1e30f, hi = -1e30f;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; lo = lo < x ? lo : x; hi = hi > x ? hi : x; }
+                tmn[i][c] = lo; tmx[i][c] = hi; cen[i][c] = t[3 + 4 * c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { tmn[i][c] = 1e30f; tmx[i][c] = -1e30f; cen[i][c] = 0.0f; }
+        }
+    }
     float bestCost = 1e30f, splitPos = 0.0f; int bestAxis = 0;
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
         float boundsMin = 1e30f, boundsMax = -1e30f;
-        for (uint32_t i = 0; i < n; ++i) { const float v = bvh_centroid(src, (size_t)first + i, a); boundsMin = boundsMin < v ? boundsMin : v; boundsMax = boundsMax > v ? boundsMax : v; }
+#pragma unroll
+        for (int i = 0; i < CRT_BVH_TINY; ++i)
+            if ((uint32_t)i < n) { const float v = cen[i][a]; boundsMin = boundsMin < v ? boundsMin : v; boundsMax = boundsMax > v ? boundsMax : v; }
         if (boundsMax == boundsMin) continue;
-        uint32_t cnt[CRT_BVH_BINS]; float bmn[CRT_BVH_BINS][3], bmx[CRT_BVH_BINS][3];
-        for (int b = 0; b < CRT_BVH_BINS; ++b) { cnt[b] = 0; for (int c = 0; c < 3; ++c) { bmn[b][c] = 1e30f; bmx[b][c] = -1e30f; } }
-        float scale = (float)CRT_BVH_BINS / (boundsMax - boundsMin);
-        for (uint32_t i = 0; i < n; ++i) {
-            const float* t = bvh_tri_f(src, (size_t)first + i);
-            int b = f2i((t[3 + 4 * a] - boundsMin) * scale);
+        const float scale = (float)CRT_BVH_BINS / (boundsMax - boundsMin);
+        int bin[CRT_BVH_TINY];
+#pragma unroll
+        for (int i = 0; i < CRT_BVH_TINY; ++i) {
+            int b = f2i((cen[i][a] - boundsMin) * scale);
             b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
             if (b < 0) b = 0;
-            cnt[b]++;
-            for (int c = 0; c < 3; ++c)
-                for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; bmn[b][c] = bmn[b][c] < x ? bmn[b][c] : x; bmx[b][c] = bmx[b][c] > x ? bmx[b][c] : x; }
+            bin[i] = (uint32_t)i < n ? b : CRT_BVH_BINS;          // absent triangles are on neither side
         }
-        float leftArea[CRT_BVH_BINS - 1], rightArea[CRT_BVH_BINS - 1];
-        int leftCount[CRT_BVH_BINS - 1], rightCount[CRT_BVH_BINS - 1];
-        int leftSum = 0, rightSum = 0;
-        float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
-        float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
-        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
-            leftSum += (int)cnt[i];
-            leftCount[i] = leftSum;
-            if (bmn[i][0] != 1e30f)
+        const float pscale = (boundsMax - boundsMin) / (float)CRT_BVH_BINS;
+#pragma unroll
+        for (int p = 0; p < CRT_BVH_BINS - 1; ++p) {
+            int leftCount = 0, rightCount = 0;
+            float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
+            float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
+#pragma unroll
+            for (int i = 0; i < CRT_BVH_TINY; ++i) {
+                const bool isL = bin[i] <= p, isR = bin[i] > p && bin[i] < CRT_BVH_BINS;
+                leftCount += isL ? 1 : 0; rightCount += isR ? 1 : 0;
+#pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    lmn[c] = lmn[c] < bmn[i][c] ? lmn[c] : bmn[i][c]; lmx[c] = lmx[c] > bmn[i][c] ? lmx[c] : bmn[i][c];
-                    lmn[c] = lmn[c] < bmx[i][c] ? lmn[c] : bmx[i][c]; lmx[c] = lmx[c] > bmx[i][c] ? lmx[c] : bmx[i][c];
+                    if (isL) { lmn[c] = lmn[c] < tmn[i][c] ? lmn[c] : tmn[i][c]; lmx[c] = lmx[c] > tmx[i][c] ? lmx[c] : tmx[i][c]; }
+                    if (isR) { rmn[c] = rmn[c] < tmn[i][c] ? rmn[c] : tmn[i][c]; rmx[c] = rmx[c] > tmx[i][c] ? rmx[c] : tmx[i][c]; }
                 }
-            leftArea[i] = bvh_area(lmn, lmx);
-            const int rb = CRT_BVH_BINS - 1 - i;
-            rightSum += (int)cnt[rb];
-            rightCount[CRT_BVH_BINS - 2 - i] = rightSum;
-            if (bmn[rb][0] != 1e30f)
-                for (int c = 0; c < 3; ++c) {
-                    rmn[c] = rmn[c] < bmn[rb][c] ? rmn[c] : bmn[rb][c]; rmx[c] = rmx[c] > bmn[rb][c] ? rmx[c] : bmn[rb][c];
-                    rmn[c] = rmn[c] < bmx[rb][c] ? rmn[c] : bmx[rb][c]; rmx[c] = rmx[c] > bmx[rb][c] ? rmx[c] : bmx[rb][c];
-                }
-            rightArea[CRT_BVH_BINS - 2 - i] = bvh_area(rmn, rmx);
-        }
-        scale = (boundsMax - boundsMin) / (float)CRT_BVH_BINS;
-        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
-            const float planeCost = (float)leftCount[i] * leftArea[i] + (float)rightCount[i] * rightArea[i];
-            if (planeCost < bestCost) { splitPos = boundsMin + scale * (float)(i + 1); bestAxis = a; bestCost = planeCost; }
+            }
+            const float planeCost = (float)leftCount * bvh_area(lmn, lmx) + (float)rightCount * bvh_area(rmn, rmx);
+            if (planeCost < bestCost) { splitPos = boundsMin + pscale * (float)(p + 1); bestAxis = a; bestCost = planeCost; }
         }
     }
     const float nosplitCost = (float)n * bvh_area(node.bmin, node.bmax);
-    node.axis = bestAxis; node.splitPos = splitPos;
-    if (bestCost >= nosplitCost) {                             // leaf: same order in both buffers
+    const bool isLeaf = bestCost >= nosplitCost;
+    if (live) { node.axis = bestAxis; node.splitPos = splitPos; }
+    if (live && isLeaf) {                                      // leaf: same order in both buffers
         node.state = 2u;
         for (uint32_t i = 0; i < n; ++i) bvh_copy_tri(dst, (size_t)first + i, src, (size_t)first + i);
-        return;
     }
-    // the partition loop on an index permutation (BVH.cpp:185-192), then one copy per triangle
-    uint32_t perm[CRT_BVH_TINY];
-    for (uint32_t i = 0; i < n; ++i) perm[i] = i;
-    int i = 0, j = (int)n - 1;
+    // the partition loop (BVH.cpp:185-192) on an index permutation packed four bits per entry, then one copy per triangle
+    uint32_t left = 0;                                         // bit i: centroid of triangle i is left of the plane
+#pragma unroll
+    for (int i = 0; i < CRT_BVH_TINY; ++i) {
+        const float c = bestAxis == 0 ? cen[i][0] : (bestAxis == 1 ? cen[i][1] : cen[i][2]);
+        if ((uint32_t)i < n && c < splitPos) left |= 1u << i;
+    }
+    uint32_t perm = 0x76543210u;
+    int i = 0, j = (live && !isLeaf) ? (int)n - 1 : -1;
     while (i <= j) {
-        if (bvh_centroid(src, (size_t)first + perm[i], bestAxis) < splitPos) i++;
-        else { const uint32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t; j--; }
+        const uint32_t pi = (perm >> (4 * i)) & 15u;
+        if ((left >> pi) & 1u) i++;
+        else {
+            const uint32_t pj = (perm >> (4 * j)) & 15u;
+            perm = (perm & ~((15u << (4 * i)) | (15u << (4 * j)))) | (pj << (4 * i)) | (pi << (4 * j));
+            j--;
+        }
     }
     const uint32_t L = (uint32_t)i;
-    for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(dst, (size_t)first + x, src, (size_t)first + perm[x]);
-    if (L == 0 || L == n) {
-        node.state = 3u;
-        for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(src, (size_t)first + x, dst, (size_t)first + x);
-    } else {
-        node.state = 1u;
-        bvh_new_children(nodes, node, first, L, n, scal, next);
+    const bool tried = live && !isLeaf, split = tried && L != 0 && L != n;
+    if (tried) {
+        for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(dst, (size_t)first + x, src, (size_t)first + ((perm >> (4 * x)) & 15u));
+        if (!split) {                                          // BVH.cpp:194: stays a leaf, triangles stay permuted -> both buffers
+            node.state = 3u;
+            for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(src, (size_t)first + x, dst, (size_t)first + x);
+        } else node.state = 1u;
     }
+    // one atomic per wave: both children of a TINY node are TINY
+    const unsigned long long m = __ballot(split);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(packed, CRT_BVH_PACK_TINY(2u * (uint32_t)__popcll(m)));
+    base = (unsigned long long)__shfl((long long)base, __ffsll((long long)m) - 1, 64);
+    if (split) bvh_new_children(nodes, node, first, L, n, levelEnd, base + CRT_BVH_PACK_TINY(2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull))), next);
 }
 
 // descendants, bottom-up: one launch per level, deepest first

@@ -559,7 +559,7 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     const size_t offLists = (offRank + 3 * total * sizeof(uint32_t) + 255) & ~(size_t)255;
     const size_t listCap = total + (size_t)numMeshes;                              // a level never has more nodes than triangles
     const size_t offSmall = (offLists + 6 * listCap * sizeof(uint32_t) + 255) & ~(size_t)255;
-    const size_t need = offSmall + (2 * (size_t)numMeshes + 8) * sizeof(uint32_t);
+    const size_t need = offSmall + (2 * (size_t)numMeshes + 8) * sizeof(uint32_t) + sizeof(unsigned long long);
     if (need > g.buildBytes) {
         if (g.buildBuf) (void)hipFree(g.buildBuf);
         g.buildBuf = nullptr; g.buildBytes = 0;
@@ -577,7 +577,8 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     for (int p = 0; p < 2; ++p) for (int c = 0; c < 3; ++c) lists[p].list[c] = listMem + ((size_t)p * 3 + (size_t)c) * listCap;
     uint32_t* dCounts = reinterpret_cast<uint32_t*>(base + offSmall);
     uint32_t* dRoots = dCounts + numMeshes;
-    uint32_t* dScal = dRoots + numMeshes;                                          // [0] next node id, [1..3] next level's list sizes, [4] nodes used
+    uint32_t* dScal = dRoots + numMeshes;                                          // [0] nodes used
+    unsigned long long* dPacked = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(dScal + 2) + 7) & ~(uintptr_t)7);   // next level's list sizes (crt_bvh_build.h)
     hipStream_t st = g.stream;
     HIPCHK(hipMemcpyAsync(dCounts, meshTriCounts, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     // level 0 = the roots, classified here
@@ -608,19 +609,19 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     while (end > begin) {
         levels.push_back(std::make_pair(begin, end));
         const CrtBuildLists& L = lists[cur]; const CrtBuildLists& N = lists[cur ^ 1];
-        uint32_t hs[4] = { end, 0u, 0u, 0u };
-        HIPCHK(hipMemcpyAsync(dScal, hs, sizeof hs, hipMemcpyHostToDevice, st));
+        unsigned long long hp = 0;
+        HIPCHK(hipMemsetAsync(dPacked, 0, sizeof hp, st));
         if (cnt[0]) { crt_bvh_split<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src);
-                      crt_bvh_partition<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src, dst, (uint32_t)firstTri, rank, holes, backL, dScal, N); }
+                      crt_bvh_partition<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src, dst, (uint32_t)firstTri, rank, holes, backL, end, dPacked, N); }
         if (cnt[1]) { crt_bvh_split<<<cnt[1], 64, 0, st>>>(bn, L.list[1], src);
-                      crt_bvh_partition<<<cnt[1], 64, 0, st>>>(bn, L.list[1], src, dst, (uint32_t)firstTri, rank, holes, backL, dScal, N); }
-        if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, dScal, N);
+                      crt_bvh_partition<<<cnt[1], 64, 0, st>>>(bn, L.list[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, dPacked, N); }
+        if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, dPacked, N);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(hs, dScal, sizeof hs, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&hp, dPacked, sizeof hp, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        const uint32_t newEnd = hs[0];
-        if (newEnd > (uint32_t)maxNodes || hs[1] + hs[2] + hs[3] != newEnd - end) return CRT_E_OUT_OF_RANGE;
-        cnt[0] = hs[1]; cnt[1] = hs[2]; cnt[2] = hs[3];
+        for (int c = 0; c < 3; ++c) cnt[c] = bvh_unpack(hp, c);
+        const uint32_t newEnd = end + cnt[0] + cnt[1] + cnt[2];
+        if (newEnd > (uint32_t)maxNodes) return CRT_E_OUT_OF_RANGE;
         bounds(N, cnt, dst);
         begin = end; end = newEnd;
         CrtTri* t = src; src = dst; dst = t;
@@ -631,14 +632,14 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
         const uint32_t c = levels[l].second - levels[l].first;
         crt_bvh_count_desc<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
     }
-    crt_bvh_number_roots<<<1, 1, 0, st>>>(bn, numMeshes, (uint32_t)firstNode, dRoots, dScal + 4);
+    crt_bvh_number_roots<<<1, 1, 0, st>>>(bn, numMeshes, (uint32_t)firstNode, dRoots, dScal);
     for (size_t l = 0; l < levels.size(); ++l) {
         const uint32_t c = levels[l].second - levels[l].first;
         crt_bvh_number_children<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
     }
     HIPCHK(hipGetLastError());
     uint32_t used = 0;
-    HIPCHK(hipMemcpyAsync(&used, dScal + 4, sizeof used, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&used, dScal, sizeof used, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (used != numBuilt || firstNode + used > g.nodeCap) return CRT_E_OUT_OF_RANGE;
     crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, g.rawNodes);
