@@ -5,9 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One *step* = one frame through the hot path: crt_render (RayGen fused into Trace, both bounces) on a
-scene that is already resident in HBM. By default two frames are in flight (CRT_RENDER_ASYNC: frame
-k+1 is submitted while frame k runs, on its own HIP stream and output buffer, so the long-ray tail of
-one frame is hidden behind the next); all K frames are complete before the clock stops.
+scene that is already resident in HBM. By default three frames are in flight (CRT_RENDER_ASYNC: frames
+k+1, k+2 are submitted while frame k runs, each on its own HIP stream and output buffer, so the long-ray
+tail of one frame is hidden behind the next); all K frames are complete before the clock stops.
 `--frames-in-flight 1` gives the reference's Render()+clFinish per frame (Renderer.cpp:305-367).
 Workload:
   N == 1 : BASELINE config 4 -- `multi-1M` (8 meshes, 1,000,960 triangles, 16 instances, textures),
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--band-rows", type=int, default=16)
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="1 = synchronous frames (Render()+clFinish), 2..4 = pipelined")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="1 = synchronous frames (Render()+clFinish), 2..4 = pipelined")
     ap.add_argument("--shadows", action="store_true", help="extension: one any-hit shadow ray per lit first hit (CRT_RENDER_SHADOWS); not the reference's semantics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

@@ -44,7 +44,7 @@ struct State {
     char deviceName[256] = { 0 };
     // Frame slots: a synchronous frame always uses slot 0; CRT_RENDER_ASYNC frames alternate between the two slots
     // (own stream, output buffer, launch lists and events each), so the tail of one frame overlaps the next.
-    FrameSlot slot[CRT_MAX_FRAMES_IN_FLIGHT]; int nSlots = 2;
+    FrameSlot slot[CRT_MAX_FRAMES_IN_FLIGHT]; int nSlots = 3;
     hipStream_t stream = nullptr;              // == slot[0].stream: uploads, queries, diagnostics
     int cur = 0;                               // slot of the most recently submitted frame
     unsigned asyncSeq = 0; bool othersBusy = false;   // frames possibly running on slots > 0
@@ -331,7 +331,7 @@ int crt_init(int device, int width, int height)
     }
     HIPCHK(hipEventCreate(&g.statStart));
     g.stream = g.slot[0].stream; g.cur = 0; g.asyncSeq = 0; g.othersBusy = false;
-    { const char* e = getenv("CRT_FRAMES_IN_FLIGHT"); g.nSlots = e ? atoi(e) : 2; if (g.nSlots < 1) g.nSlots = 1; if (g.nSlots > CRT_MAX_FRAMES_IN_FLIGHT) g.nSlots = CRT_MAX_FRAMES_IN_FLIGHT; }
+    { const char* e = getenv("CRT_FRAMES_IN_FLIGHT"); g.nSlots = e ? atoi(e) : 3; if (g.nSlots < 1) g.nSlots = 1; if (g.nSlots > CRT_MAX_FRAMES_IN_FLIGHT) g.nSlots = CRT_MAX_FRAMES_IN_FLIGHT; }
 
     g.triCap = (size_t)CRT_MAX_TRIANGLES * 2;           // ResourceManager.cpp:158
     g.nodeCap = (size_t)CRT_MAX_TRIANGLES * 2;          // ResourceManager.cpp:159 (MAX_BVHMEMORY * 2)
@@ -772,14 +772,16 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
         }
     } else {
-        // default megakernel: <COUNT, STAMP, SHADOW, WIDE>. WIDE (6 waves/SIMD) serves frames submitted with
-        // CRT_RENDER_ASYNC that fill the machine at least four times over -- throughput decides there. A synchronous
-        // frame, or a small share of a frame (8 ranks at 3840x2160: 2.6 rounds of waves), is decided by its slowest
-        // waves and runs faster on the 5-waves/SIMD flavour (measured: 37.8 vs 41 Gray/s predicted for 8 ranks).
+        // default megakernel: <COUNT, STAMP, SHADOW, WIDE>. WIDE (6 waves/SIMD) serves CRT_RENDER_ASYNC frames when the
+        // frames in flight together fill the machine about 6.5 times over -- throughput decides there. A synchronous
+        // frame, or little work in flight (8 ranks at 3840x2160 with two slots: 5.3 rounds of waves), is decided by
+        // its slowest waves and runs faster on the 5-waves/SIMD flavour. Measured, predicted Gray/s for 8 ranks:
+        // 2 slots narrow 41.6 / wide 37.8; 3 slots narrow 44.7 / wide 46.6.
         const size_t tiles = (size_t)F.ownedTileRows * (size_t)F.tilesX;
         const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0;
         const bool wide = g.forceWide >= 0 ? g.forceWide != 0
-                                           : ((flags & CRT_RENDER_ASYNC) != 0 && tiles >= (size_t)4 * (size_t)g.numCUs * 4 * CRT_WAVES_PER_SIMD_WIDE);
+                                           : ((flags & CRT_RENDER_ASYNC) != 0
+                                              && 2 * tiles * (size_t)g.nSlots >= (size_t)13 * (size_t)g.numCUs * 4 * CRT_WAVES_PER_SIMD_WIDE);
 #define CRT_LAUNCH_TRACE(C_, S_, W_) crt_trace_kernel<C_, false, S_, W_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters)
         if (count) { if (shadow) { if (wide) CRT_LAUNCH_TRACE(true, true, true); else CRT_LAUNCH_TRACE(true, true, false); }
                      else        { if (wide) CRT_LAUNCH_TRACE(true, false, true); else CRT_LAUNCH_TRACE(true, false, false); } }

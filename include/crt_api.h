@@ -98,9 +98,9 @@ int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count);
 
 /* Renderer.cpp:337-367: RayGen + Trace (+ PostProcess) for one frame, then (unless ASYNC) wait.
  * invView / invProj are the camera's inverse matrices, row-major (hazard H10: taken as inputs).
- * Frames in flight (no reference counterpart): consecutive CRT_RENDER_ASYNC frames alternate between two frame
- * slots (CRT_FRAMES_IN_FLIGHT=1..4 in the environment, default 2), each with its own HIP stream, output buffer and
- * launch lists, so two frames run concurrently and the long-ray tail of one is hidden behind the other; the call
+ * Frames in flight (no reference counterpart): consecutive CRT_RENDER_ASYNC frames rotate over three frame
+ * slots (CRT_FRAMES_IN_FLIGHT=1..4 in the environment, default 3), each with its own HIP stream, output buffer and
+ * launch lists, so frames run concurrently and the long-ray tail of one is hidden behind the others; the call
  * blocks only to keep at most two frames queued per slot. Uploads, resize, queries and reads wait for every frame
  * in flight first, so scene edits between frames stay ordered. crt_read_output* and crt_output_device_ptr refer
  * to the most recently submitted frame. */
