@@ -1,0 +1,97 @@
+"""CPU-only checks of the two things the GPU path adds beyond upstream's behaviour and that the oracle / the header
+comments define: the shadow-ray extension (orc_trace_ex) and the closed form of BuildBVH's partition loop that
+crt_build_bvh evaluates in parallel (clraytracer_amd/csrc/crt_bvh_build.h)."""
+import numpy as np
+import pytest
+
+from clraytracer_amd import driver, scenes
+import oracle_lib
+from util import bits
+
+
+def test_shadow_extension_is_a_pure_addition(nthreads):
+    """Shadow rays are traced for lit first hits only, are counted on top of upstream's rays, and can only remove the
+    energy-weighted diffuse term of the second bounce: pixels whose shadow ray is unoccluded are bit-identical."""
+    sc = scenes.get("tiny")
+    with driver.Session(160, 96, host_only=True) as s:
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        rays = orc.raygen(160, 96, iv, ip)
+        plain, st0 = orc.trace(rays, pos, sc.sun_angle)
+        shad, st1 = orc.trace(rays, pos, sc.sun_angle, shadows=True)
+        assert st0["shadowRays"] == 0 and st0["shadowHits"] == 0
+        assert 0 < st1["shadowHits"] <= st1["shadowRays"] <= st0["hits"]
+        assert st1["rays"] == st0["rays"] + st1["shadowRays"]
+        for k in ("primary", "secondary", "hits", "misses"):
+            assert st1[k] == st0[k]
+        changed = (bits(plain) != bits(shad)).any(-1)
+        assert 0 < changed.sum() <= st1["shadowHits"]
+        # an occluded first hit loses (part of) what the second bounce added: never brighter
+        assert np.all(shad[changed][:, :3] <= plain[changed][:, :3])
+        # row ranges compose (the multi-GPU band split relies on it)
+        top, sa = orc.trace(rays, pos, sc.sun_angle, row0=0, row1=40, shadows=True)
+        bot, sb = orc.trace(rays, pos, sc.sun_angle, row0=40, row1=96, shadows=True)
+        assert np.array_equal(bits(top[:40]), bits(shad[:40])) and np.array_equal(bits(bot[40:]), bits(shad[40:]))
+        assert sa["shadowRays"] + sb["shadowRays"] == st1["shadowRays"] and sa["shadowHits"] + sb["shadowHits"] == st1["shadowHits"]
+
+
+def partition_loop(left):
+    """BVH.cpp:185-192 on an index array; `left[k]` = centroid of element k is below the split plane."""
+    perm = list(range(len(left)))
+    i, j = 0, len(left) - 1
+    while i <= j:
+        if left[perm[i]]:
+            i += 1
+        else:
+            perm[i], perm[j] = perm[j], perm[i]
+            j -= 1
+    return perm, i
+
+
+def partition_closed_form(left):
+    """The same permutation from two prefix sums and two tables (crt_bvh_build.h header): dest[x] for every x."""
+    left = np.asarray(left, bool)
+    n = len(left)
+    L = int(left.sum())
+    holes = [x for x in range(L) if not left[x]]                      # r_1 < r_2 < ...: right-class positions below L
+    backL = [n - 1 - x for x in range(n - 1, L - 1, -1) if left[x]]   # l_1 < l_2 < ...: back-order indices of left-class elements
+    G = len(holes)
+    assert G == len(backL)
+    dest = np.zeros(n, np.int64)
+    m_front = 0
+    rank_back = {}
+    for m, y in enumerate(backL):
+        rank_back[n - 1 - y] = m
+    for x in range(n):
+        if x < L:
+            if left[x]:
+                dest[x] = x
+            else:
+                slot = 0 if m_front == 0 else backL[m_front - 1] + 1
+                dest[x] = n - 1 - slot
+                m_front += 1
+        elif left[x]:
+            dest[x] = holes[rank_back[x]]
+        elif x == L:
+            slot = 0 if G == 0 else backL[G - 1] + 1
+            dest[x] = n - 1 - slot
+        else:
+            dest[x] = x - 1
+    perm = np.zeros(n, np.int64)
+    perm[dest] = np.arange(n)
+    return perm.tolist(), L
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 13, 64, 257])
+def test_partition_closed_form_equals_the_loop(n):
+    rng = np.random.RandomState(n)
+    cases = [np.zeros(n, bool), np.ones(n, bool)]
+    if n <= 13:
+        cases += [np.array([(k >> b) & 1 for b in range(n)], bool) for k in range(1 << n)] if n <= 8 else []
+    for p in (0.05, 0.3, 0.5, 0.7, 0.95):
+        cases += [rng.rand(n) < p for _ in range(40)]
+    for left in cases:
+        want, wl = partition_loop(list(left))
+        got, gl = partition_closed_form(left)
+        assert gl == wl and got == want, left
