@@ -78,6 +78,7 @@ HIP_API = {
     "crt_query_hits": (C.c_int, [_vp, _vp, C.c_int, C.c_uint32, _vp]),
     "crt_read_output": (C.c_int, [_vp, _sz]),
     "crt_read_output_rows": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "crt_read_output_rgba8": (C.c_int, [_vp, _sz]),
     "crt_read_rays": (C.c_int, [_vp, _sz]),
     "crt_output_device_ptr": (_vp, []),
     "crt_owned_rows": (C.c_int, []),
@@ -116,6 +117,8 @@ HOST_API = {
     "crth_resize": (None, [C.c_int, C.c_int]),
     "crth_set_postprocess": (None, [C.c_int]),
     "crth_set_shadows": (None, [C.c_int]),
+    "crth_set_unorm8": (None, [C.c_int]),
+    "crth_map_output_rgba8": (_vp, []),
     "crth_set_pipelined": (None, [C.c_int]),
     "crth_set_row_bands": (None, [C.c_int, C.c_int, C.c_int]),
     "crth_render": (C.c_uint, [_f]),

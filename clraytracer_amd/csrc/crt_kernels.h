@@ -327,6 +327,31 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_postprocess_kernel(CrtFrame F, 
     img[idx] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
 }
 
+// Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef):
+// convert_uchar_sat_rte(x * 255) / 255 per channel, in place (CRT_RENDER_UNORM8), and the packed bytes.
+__device__ __forceinline__ uint32_t unorm8(float x)
+{
+    const float v = x * 255.0f;
+    if (!(v == v) || v <= 0.0f) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (uint32_t)rintf(v);
+}
+__global__ __launch_bounds__(CRT_BLOCK) void crt_quantize_kernel(CrtFrame F, float4* __restrict__ img)
+{
+    int px, py;
+    if (!lane_pixel(F, px, py)) return;
+    const size_t idx = (size_t)py * (size_t)F.width + (size_t)px;
+    const float4 p = img[idx];
+    img[idx] = make_float4((float)unorm8(p.x) / 255.0f, (float)unorm8(p.y) / 255.0f, (float)unorm8(p.z) / 255.0f, (float)unorm8(p.w) / 255.0f);
+}
+__global__ void crt_pack_unorm8_kernel(const float4* __restrict__ img, uint32_t* __restrict__ out, size_t pixels)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= pixels) return;
+    const float4 p = img[k];
+    out[k] = unorm8(p.x) | (unorm8(p.y) << 8) | (unorm8(p.z) << 16) | (unorm8(p.w) << 24);
+}
+
 // closest-hit query over explicit rays (hit-record parity)
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
                                                               const float* __restrict__ dirs, int n,

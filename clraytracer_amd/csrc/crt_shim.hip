@@ -830,7 +830,7 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
         g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0;
     }
     es.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
-    es.evPost = (flags & CRT_RENDER_POSTPROCESS) != 0;
+    es.evPost = (flags & (CRT_RENDER_POSTPROCESS | CRT_RENDER_UNORM8)) != 0;
     HIPCHK(hipEventRecord(es.ev[0], fs.stream));
     if (es.evRaygen) {
         crt_raygen_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, g.rays);
@@ -841,7 +841,11 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     if (rc) return rc;
     HIPCHK(hipEventRecord(es.ev[2], fs.stream));
     if (es.evPost) {
-        crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+        // upstream: Trace write_imagef's into an RGBA8 texture, PostProcess read_imagef's it back and write_imagef's again
+        const bool unorm = (flags & CRT_RENDER_UNORM8) != 0, post = (flags & CRT_RENDER_POSTPROCESS) != 0;
+        if (unorm) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+        if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+        if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(es.ev[3], fs.stream));
     }
@@ -908,6 +912,25 @@ int crt_read_output_rows(float* dst, int row0, int rows)
     if (!dst || row0 < 0 || rows < 0 || row0 + rows > g.height) return CRT_E_BAD_ARGUMENT;
     RCCHK(sync_all());
     HIPCHK(hipMemcpy(dst, g.slot[g.cur].out + (size_t)row0 * (size_t)g.width, (size_t)rows * (size_t)g.width * sizeof(float4), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_read_output_rgba8(uint8_t* dst, size_t bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    const size_t pixels = (size_t)g.width * (size_t)g.height;
+    if (!dst || bytes != pixels * 4) return CRT_E_BAD_ARGUMENT;
+    RCCHK(sync_all());
+    if (pixels * 4 > g.queryBytes) {                       // shares the query scratch buffer
+        if (g.queryBuf) (void)hipFree(g.queryBuf);
+        g.queryBuf = nullptr; g.queryBytes = 0;
+        HIPCHK(hipMalloc(&g.queryBuf, pixels * 4));
+        g.queryBytes = pixels * 4;
+    }
+    crt_pack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, g.stream>>>(g.slot[g.cur].out, static_cast<uint32_t*>(g.queryBuf), pixels);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst, g.queryBuf, pixels * 4, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
     return CRT_OK;
 }
 

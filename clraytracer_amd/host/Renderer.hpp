@@ -34,6 +34,8 @@ namespace Renderer
     // ---- additions for the headless build ----
     Camera& EditCamera();                 // set position/Front, then RecalculateView()
     void SetPostProcess(bool enabled);    // PostProcess is on upstream; parity is judged pre-post
+    void SetUnorm8(bool enabled);         // quantise like upstream's RGBA8 render target (hazard H8); MapOutputRGBA8() returns the bytes
+    const unsigned char* MapOutputRGBA8();
     void SetShadows(bool enabled);        // extension: the shadow ray upstream leaves as a TODO (kernel_main.cl:256-258); off by default
     void SetPipelined(bool enabled);      // Render() returns without waiting (frames in flight); MapOutput()/uploads wait. Off by default (upstream clFinish()es)
     void SetTime(float seconds);          // TraceArgs.time (Window::GetTime upstream)

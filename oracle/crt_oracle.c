@@ -579,6 +579,40 @@ void orc_postprocess(float* rgba, int width, int height, int row0, int row1)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Hazard H8: upstream's render target is a GL_RGBA 8-bit UNORM texture (Renderer.cpp:63,192), so write_imagef
+ * (kernel_main.cl:274,358) stores convert_uchar_sat_rte(x * 255) per channel and read_imagef (kernel_main.cl:347)
+ * returns c / 255. orc_quantize_unorm8 applies that store+load to a float frame in place (OpenCL 1.2 spec 8.3.1.1:
+ * NaN -> 0, round to nearest even, saturate); orc_pack_unorm8 emits the bytes.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint8_t unorm8(float x)
+{
+    float v = x * 255.0f;
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)rintf(v); /* default rounding mode: to nearest even */
+}
+
+void orc_quantize_unorm8(float* rgba, int width, int height, int row0, int row1)
+{
+    (void)height;
+    for (int j = row0; j < row1; ++j)
+        for (int i = 0; i < width; ++i) {
+            float* p = rgba + 4 * ((size_t)j * (size_t)width + (size_t)i);
+            for (int c = 0; c < 4; ++c) p[c] = (float)unorm8(p[c]) / 255.0f;
+        }
+}
+
+void orc_pack_unorm8(const float* rgba, uint8_t* out, int width, int height, int row0, int row1)
+{
+    (void)height;
+    for (int j = row0; j < row1; ++j)
+        for (int i = 0; i < width; ++i) {
+            const size_t k = 4 * ((size_t)j * (size_t)width + (size_t)i);
+            for (int c = 0; c < 4; ++c) out[k + c] = unorm8(rgba[k + c]);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
  * CPURayTrace.cpp:186-249  CPU_RayCast (one primary ray -> HitRecord, no lighting)
  * _mm_rcp_ps (vendor-specific 12-bit estimate) is pinned to IEEE 1/x.
  * ---------------------------------------------------------------------------------------- */

@@ -112,6 +112,10 @@ void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, i
 void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                   int row0, int row1, float* out, OrcStats* stats, int nthreads, int shadows);
 void orc_postprocess(float* rgba, int width, int height, int row0, int row1);
+/* Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef), in place on a
+ * float frame; and the bytes themselves. Upstream's displayed frame = pack(postprocess(quantize(trace))). */
+void orc_quantize_unorm8(float* rgba, int width, int height, int row0, int row1);
+void orc_pack_unorm8(const float* rgba, uint8_t* out, int width, int height, int row0, int row1);
 /* Analysis helper: per-pixel inner visits / triangle tests (both bounces) of a full frame. */
 void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                      uint32_t* innerOut, uint32_t* triOut, int nthreads);

@@ -60,6 +60,8 @@ def lib():
         L.orc_trace_ex.argtypes = [C.POINTER(OrcScene), C.POINTER(CrtTraceArgs), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.POINTER(OrcStats), C.c_int, C.c_int]
         L.orc_postprocess.restype = None; L.orc_postprocess.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_quantize_unorm8.restype = None; L.orc_quantize_unorm8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_pack_unorm8.restype = None; L.orc_pack_unorm8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_closest_hits.restype = None
         L.orc_closest_hits.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(OrcStats), C.c_int]
         L.orc_cpu_raycast.restype = None
@@ -111,6 +113,19 @@ class Oracle:
         h, w, _ = img.shape
         lib().orc_postprocess(img.ctypes.data, w, h, row0, h if row1 is None else row1)
         return img
+
+    def quantize_unorm8(self, img):
+        img = np.ascontiguousarray(img, np.float32).copy()
+        h, w, _ = img.shape
+        lib().orc_quantize_unorm8(img.ctypes.data, w, h, 0, h)
+        return img
+
+    def pack_unorm8(self, img):
+        img = np.ascontiguousarray(img, np.float32)
+        h, w, _ = img.shape
+        out = np.zeros((h, w, 4), np.uint8)
+        lib().orc_pack_unorm8(img.ctypes.data, out.ctypes.data, w, h, 0, h)
+        return out
 
     def closest_hits(self, origins, dirs):
         from clraytracer_amd._lib import RAYHIT_DTYPE

@@ -64,3 +64,35 @@ def test_shadows_many_instances(nthreads):
         s.render_raw(SHADOWS | COUNTERS)
         assert np.array_equal(bits(s.read_output()), bits(ref)) and s.counters() == st
         assert st["shadowHits"] > 0
+
+
+@pytest.mark.parametrize("name", ["tiny", "sponza-class-250k"])
+def test_unorm8_render_target_like_upstream(name, nthreads):
+    """CRT_RENDER_UNORM8 (hazard H8): the frame upstream actually displays -- Trace quantised into the RGBA8 texture,
+    PostProcess reading that back, the result quantised again -- against the oracle composition. The quantised Trace
+    stage is bit-exact; after PostProcess (powf: <= 2e-5 apart) a byte may differ by one code at a rounding boundary."""
+    sc = scenes.get(name)
+    UNORM8, POST = 64, 1
+    with driver.Session(320, 184, device=0) as s:
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        pre, _ = orc.trace(orc.raygen(320, 184, iv, ip), pos, sc.sun_angle)
+        q = orc.quantize_unorm8(pre)
+        s.render_raw(UNORM8)
+        assert np.array_equal(bits(s.read_output()), bits(q))
+        rgba = np.zeros((184, 320, 4), np.uint8)
+        from clraytracer_amd import _lib
+        assert _lib.hip().crt_read_output_rgba8(rgba.ctypes.data, rgba.size) == 0
+        assert np.array_equal(rgba, orc.pack_unorm8(pre))
+        want = orc.pack_unorm8(orc.postprocess(q))
+        s.render_raw(UNORM8 | POST)
+        assert _lib.hip().crt_read_output_rgba8(rgba.ctypes.data, rgba.size) == 0
+        d = np.abs(rgba.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())
+        # the mirrored Renderer: upstream's Render() = UNORM8 target + PostProcess
+        s.h.crth_set_unorm8(1)
+        s.render(postprocess=True)
+        got = _lib.as_array(s.h.crth_map_output_rgba8(), 320 * 184 * 4, np.uint8).reshape(184, 320, 4)
+        s.h.crth_set_unorm8(0)
+        assert np.array_equal(got, rgba)

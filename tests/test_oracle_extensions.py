@@ -95,3 +95,17 @@ def test_partition_closed_form_equals_the_loop(n):
         want, wl = partition_loop(list(left))
         got, gl = partition_closed_form(left)
         assert gl == wl and got == want, left
+
+
+def test_unorm8_store_load_matches_the_opencl_rule():
+    """Hazard H8: write_imagef to an RGBA8-UNORM image = convert_uchar_sat_rte(x * 255); read_imagef = c / 255."""
+    L = oracle_lib.lib()
+    x = np.array([[[-1.0, 0.0, 0.5 / 255, 1.5 / 255], [2.5 / 255, 0.999, 1.0, 7.3], [np.nan, np.inf, -np.inf, 254.5 / 255],
+                   [0.25, 0.5, 0.75, 1e-9]]], np.float32)
+    want = np.array([[[0, 0, 0, 2], [2, 255, 255, 255], [0, 255, 0, 254], [64, 128, 191, 0]]], np.uint8)   # ties to even: .5->0, 1.5->2, 2.5->2, 254.5->254
+    orc = oracle_lib.Oracle.__new__(oracle_lib.Oracle)
+    got = orc.pack_unorm8(x)
+    assert np.array_equal(got, want)
+    q = orc.quantize_unorm8(x)
+    assert np.array_equal(q.view(np.uint32), (want.astype(np.float32) / np.float32(255.0)).view(np.uint32))
+    assert np.array_equal(orc.pack_unorm8(q), want)            # idempotent
