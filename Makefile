@@ -10,7 +10,7 @@ CXXFLAGS = -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -
 
 HIP_SO = clraytracer_amd/csrc/libcrt_hip.so
 HOST_SO = clraytracer_amd/host/libcrt_host.so
-HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp)
+HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp MeshCache.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp)
 HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
 
 EXAMPLE = examples/crt_headless

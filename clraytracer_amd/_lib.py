@@ -101,6 +101,9 @@ HOST_API = {
     "crth_import_mesh": (C.c_int, [C.c_char_p]),
     "crth_push_meshes": (None, []),
     "crth_set_device_bvh_build": (None, [C.c_int]),
+    "crth_set_mesh_cache": (None, [C.c_int]),
+    "crth_qlz_decompress": (C.c_size_t, [_vp, _sz, _vp, _sz]),
+    "crth_qlz_store": (C.c_size_t, [_vp, _sz, _vp]),
     "crth_push_textures": (None, []),
     "crth_push_materials": (None, []),
     "crth_create_material": (C.c_int, [C.c_int]),

@@ -158,19 +158,37 @@ bool parse_mtl(ObjMesh* mesh, size_t msz, unsigned char materialMap[512])
 void AssetManager_Initialize() {}
 void AssetManager_Destroy() {}
 
-ObjMesh* AssetManager_ImportMesh(const char* path, Tri* triArena)
+static ObjMesh* AssetManager_ImportObj(const char* path, Tri* triArena, size_t maxTris);
+
+// AssetManager.cpp:363-381: prefer `<stem>.clm`, else parse the OBJ and leave a `.clm` behind for the next run
+ObjMesh* AssetManager_ImportMesh(const char* path, Tri* triArena, size_t maxTris)
+{
+    const std::string clm = with_extension(path, "clm");
+    if (AssetManager_MeshCacheEnabled() && MeshCache_IsFresh(clm.c_str(), path)) {
+        if (ObjMesh* cached = AssetManager_LoadMeshFromDisk(clm.c_str(), triArena, maxTris)) return cached;
+        std::fprintf(stderr, "[AssetManager] ignoring %s, importing %s\n", clm.c_str(), path);
+    }
+    ObjMesh* mesh = AssetManager_ImportObj(path, triArena, maxTris);
+    if (mesh && AssetManager_MeshCacheEnabled() && !AssetManager_SaveMeshToDisk(clm.c_str(), mesh))
+        std::fprintf(stderr, "[AssetManager] could not write %s (continuing without the cache)\n", clm.c_str());
+    return mesh;
+}
+
+static ObjMesh* AssetManager_ImportObj(const char* path, Tri* triArena, size_t maxTris)
 {
     std::vector<char> obj;
     if (!read_file(path, obj)) { std::fprintf(stderr, "[AssetManager] mesh file does not exist: %s\n", path); return nullptr; }
 
     ObjMesh* mesh = new ObjMesh;
-    mesh->name = nullptr; mesh->tris = triArena; mesh->numTris = 0; mesh->numMaterials = 0; mesh->mtlText = nullptr;
+    mesh->name = nullptr; mesh->tris = triArena; mesh->numTris = 0; mesh->numMaterials = 0; mesh->mtlText = nullptr; mesh->mtlSize = 0;
+    std::memset(mesh->materials, 0, sizeof mesh->materials);
 
     unsigned char materialMap[512] = { 0 };
     std::vector<char> mtl;
     if (read_file(with_extension(path, "mtl"), mtl) && mtl.size() > 1) {
         mesh->mtlText = (char*)std::malloc(mtl.size());
         std::memcpy(mesh->mtlText, mtl.data(), mtl.size());
+        mesh->mtlSize = (unsigned)mtl.size();
         if (!parse_mtl(mesh, mtl.size() - 1, materialMap)) { AssetManager_DestroyMesh(mesh); return nullptr; }
     }
 
@@ -212,6 +230,7 @@ ObjMesh* AssetManager_ImportMesh(const char* path, Tri* triArena)
         else if (curr[0] == 'f' && curr[1] == ' ') {
             curr += 2;
             if (mesh->numTris + 1 >= 1000000) return fail("too many triangles for one mesh (>= 1,000,000)");
+            if ((size_t)mesh->numTris + 1 > maxTris) return fail("the triangle arena is full");
             Tri* tri = mesh->tris + mesh->numTris++;
             float* vert[3] = { tri->v0, tri->v1, tri->v2 };
             half* uvp[3] = { tri->uv0, tri->uv1, tri->uv2 };

@@ -1,5 +1,5 @@
 // AssetManager.hpp -- OBJ/MTL importer of the reference (AssetManager.hpp:1-42, AssetManager.cpp:90-289).
-// In scope: OBJ subset -> Tri[] + materials. The .clm/QuickLZ cache is a "next" row.
+// OBJ subset -> Tri[] + materials, and the `.clm` mesh cache with its QuickLZ stream (MeshCache.cpp).
 #pragma once
 #include "ResourceManager.hpp"
 
@@ -17,11 +17,21 @@ struct ObjMesh {
     ObjMaterial materials[32];
     int numMaterials;
     char* mtlText;
+    unsigned mtlSize;                  // bytes in mtlText (upstream passes it alongside, AssetManager.cpp:287)
 };
 
 // Returns nullptr (and logs to stderr) on failure where the reference calls exit(0).
-ObjMesh* AssetManager_ImportMesh(const char* path, Tri* triArena);
+ObjMesh* AssetManager_ImportMesh(const char* path, Tri* triArena, size_t maxTris = 1000000);   // maxTris: room left in the arena
 void AssetManager_DestroyMesh(ObjMesh* mesh);
+// `.clm` cache (AssetManager.cpp:291-361): ImportMesh prefers `<stem>.clm` when it is not older than the OBJ and writes
+// it after an OBJ import, as upstream does (upstream does not compare dates). On by default; maxTris = room in the arena.
+void AssetManager_SetMeshCache(bool enabled);
+bool AssetManager_MeshCacheEnabled();
+bool AssetManager_SaveMeshToDisk(const char* path, const ObjMesh* mesh);
+ObjMesh* AssetManager_LoadMeshFromDisk(const char* path, Tri* triArena, size_t maxTris);
+bool MeshCache_IsFresh(const char* cache, const char* source);
+size_t MeshCache_QlzDecompress(const unsigned char* src, size_t srcLen, unsigned char* dst, size_t dstCap);
+size_t MeshCache_QlzStore(const unsigned char* src, size_t size, unsigned char* dst);
 void AssetManager_Initialize();
 void AssetManager_Destroy();
 

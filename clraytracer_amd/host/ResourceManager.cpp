@@ -195,7 +195,7 @@ MeshHandle ResourceManager::ImportMesh(const char* path) // ResourceManager.cpp:
 {
     if (numMeshes >= (int)MaxMeshes) { lastError = CRT_E_OUT_OF_RANGE; return 0; }
     MeshInfo& meshInfo = meshInfos[numMeshes];
-    ObjMesh* mesh = AssetManager_ImportMesh(path, g_Triangles + numTriangles);
+    ObjMesh* mesh = AssetManager_ImportMesh(path, g_Triangles + numTriangles, MAX_TRIANGLES - numTriangles);
     if (!mesh) { lastError = CRT_E_BAD_ARGUMENT; return 0; }
     if (numTriangles + (size_t)mesh->numTris > MAX_TRIANGLES || numMaterials + mesh->numMaterials > (int)MaxMaterials) {
         std::fprintf(stderr, "[ResourceManager] mesh does not fit the arenas: %s\n", path);

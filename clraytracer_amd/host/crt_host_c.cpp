@@ -37,6 +37,9 @@ int crth_import_texture(const char* path) { return ResourceManager::ImportTextur
 int crth_import_texture_rgb8(const char* name, int w, int h, const unsigned char* rgb) { return ResourceManager::ImportTextureRGB8(name, w, h, rgb); }
 int crth_import_mesh(const char* path) { return ResourceManager::ImportMesh(path); }
 void crth_push_meshes(void) { ResourceManager::PushMeshesToGPU(); }
+void crth_set_mesh_cache(int enabled) { AssetManager_SetMeshCache(enabled != 0); }
+size_t crth_qlz_decompress(const unsigned char* src, size_t srcLen, unsigned char* dst, size_t dstCap) { return MeshCache_QlzDecompress(src, srcLen, dst, dstCap); }
+size_t crth_qlz_store(const unsigned char* src, size_t size, unsigned char* dst) { return MeshCache_QlzStore(src, size, dst); }
 void crth_set_device_bvh_build(int enabled) { ResourceManager::SetDeviceBVHBuild(enabled != 0); }
 void crth_push_textures(void) { ResourceManager::PushTexturesToGPU(); }
 void crth_push_materials(void) { ResourceManager::PushMaterialsToGPU(); }

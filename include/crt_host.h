@@ -26,6 +26,9 @@ int crth_import_texture_rgb8(const char* name, int width, int height, const unsi
 int crth_import_mesh(const char* path);                      /* ResourceManager::ImportMesh */
 void crth_push_meshes(void);                                 /* ResourceManager::PushMeshesToGPU */
 void crth_set_device_bvh_build(int enabled);                 /* ResourceManager::SetDeviceBVHBuild */
+void crth_set_mesh_cache(int enabled);                       /* AssetManager_SetMeshCache: the `.clm` cache (AssetManager.cpp:291-381), on by default */
+size_t crth_qlz_decompress(const unsigned char* src, size_t srcLen, unsigned char* dst, size_t dstCap); /* QuickLZ 1.5.0 level 1 */
+size_t crth_qlz_store(const unsigned char* src, size_t size, unsigned char* dst);                        /* stored block, size + 9 bytes */
 void crth_push_textures(void);                               /* ResourceManager::PushTexturesToGPU */
 void crth_push_materials(void);                              /* ResourceManager::PushMaterialsToGPU */
 int crth_create_material(int count);                         /* ResourceManager::CreateMaterial -> first handle, -1 on failure */

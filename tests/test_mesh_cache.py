@@ -1,0 +1,133 @@
+"""The `.clm` mesh cache (AssetManager.cpp:291-381) of the mirrored importer and its QuickLZ 1.5.0 level-1 stream.
+The product's decoder is written from the format; where the reference tree is present its own quicklz.c -- compiled
+as it lies into oracle/_ref/ (oracle/Makefile) -- provides real compressed streams and the decompression to compare with."""
+import ctypes as C
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from clraytracer_amd import _lib, driver, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libquicklz_ref.so")
+REF_ASSETS = "/root/reference/CLRayTracer/Assets"
+
+
+def qlz_decompress(data, out_len):
+    H = _lib.host()
+    src = np.frombuffer(data, np.uint8)
+    dst = np.zeros(out_len, np.uint8)
+    n = H.crth_qlz_decompress(src.ctypes.data, len(src), dst.ctypes.data, len(dst))
+    return n, dst
+
+
+def test_stored_block_round_trip():
+    H = _lib.host()
+    rng = np.random.RandomState(1)
+    for n in (1, 8, 300, 80000):
+        raw = rng.randint(0, 256, n).astype(np.uint8)
+        buf = np.zeros(n + 9, np.uint8)
+        assert H.crth_qlz_store(raw.ctypes.data, n, buf.ctypes.data) == n + 9
+        assert buf[0] == 0x46 and int.from_bytes(buf[1:5].tobytes(), "little") == n + 9 and int.from_bytes(buf[5:9].tobytes(), "little") == n
+        got_n, got = qlz_decompress(buf.tobytes(), n)
+        assert got_n == n and np.array_equal(got, raw)
+    # malformed input is refused, never read or written out of bounds
+    assert qlz_decompress(b"\x47\x10\x00\x00\x00\x40\x00\x00\x00" + b"\xff" * 7, 64)[0] == 0     # compressed flag, garbage body
+    assert qlz_decompress(b"\x46\x09\x00\x00\x00\x40\x00\x00\x00", 64)[0] == 0                   # stored, body missing
+    assert qlz_decompress(b"\x46", 64)[0] == 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libquicklz_ref.so is only built where the reference tree is mounted")
+def test_decoder_against_the_reference_codec():
+    R = C.CDLL(REF_SO)
+    R.qlz_get_setting.restype = C.c_int
+    assert R.qlz_get_setting(0) == 1 and R.qlz_get_setting(3) == 0       # level 1, no streaming buffer: what upstream ships
+    R.qlz_compress.restype = C.c_size_t
+    R.qlz_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.RandomState(7)
+    sc = scenes.get("tiny")
+    with driver.Session(64, 48, host_only=True) as s:
+        s.load_scene(sc)
+        tris = s.arenas()["tris"].copy()
+    samples = [tris.tobytes(),                                               # what a .clm holds: highly repetitive 80-B records
+               bytes(200000), b"abc" * 70000, (b"0123456789" * 10 + b"x") * 3000,
+               rng.randint(0, 4, 150000).astype(np.uint8).tobytes(),          # low entropy
+               rng.randint(0, 256, 100000).astype(np.uint8).tobytes(),        # incompressible -> stored block
+               np.repeat(rng.randint(0, 256, 3000).astype(np.uint8), rng.randint(1, 300, 3000)).tobytes(),
+               b"a", b"ab" * 5, bytes(range(256)) * 3]
+    for raw in samples:
+        state = C.create_string_buffer(R.qlz_get_setting(1))
+        comp = C.create_string_buffer(len(raw) + 400)
+        n = R.qlz_compress(raw, comp, len(raw), state)
+        assert n > 0
+        got_n, got = qlz_decompress(comp.raw[:n], len(raw))
+        assert got_n == len(raw) and got.tobytes() == raw, (len(raw), n)
+        # truncated streams are refused
+        if n > 20:
+            assert qlz_decompress(comp.raw[:n // 2], len(raw))[0] in (0,)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ASSETS), reason="the reference's shipped .clm caches are only available where the reference tree is mounted")
+@pytest.mark.parametrize("rel,min_tris", [("sphere.clm", 80), ("sponza/sponza.clm", 66447), ("sibenik/sibenik.clm", None), ("nanosuit/nanosuit.clm", None)])
+def test_loads_upstream_mesh_caches(rel, min_tris, tmp_path):
+    """The caches upstream ships (QuickLZ-compressed above 1000 triangles) load through the mirrored importer: they
+    decode to exactly numTris * 80 bytes of finite triangles and a BVH can be built over them."""
+    src = os.path.join(REF_ASSETS, rel)
+    stem = os.path.splitext(os.path.basename(rel))[0]
+    shutil.copy(src, tmp_path / (stem + ".clm"))                             # no .obj next to it: only the cache exists
+    with driver.Session(64, 48, host_only=True) as s:
+        h = s.h
+        h.crth_prepare_meshes()
+        import struct
+        want_tris, want_mats = struct.unpack_from("<ii", open(src, "rb").read(12), 4)
+        handle = h.crth_import_mesh(str(tmp_path / (stem + ".obj")).encode())
+        # (the MTL text names JPEG textures, which this build does not decode: those imports fail and fall back to the
+        #  default texture -- the mesh itself must be there)
+        info = np.zeros(4, np.uint32)
+        h.crth_mesh_info(handle, info.ctypes.data)
+        assert info[0] == want_tris and info[3] == want_mats and (min_tris is None or info[0] == min_tris)
+        tris = _lib.as_array(h.crth_triangles(), h.crth_num_triangles(), _lib.TRI_DTYPE)
+        assert len(tris) == info[0]
+        for k in ("v0", "v1", "v2"):
+            assert np.isfinite(tris[k]).all() and np.abs(tris[k]).max() < 1e6
+        print(f"{rel}: {info[0]} triangles, {info[3]} materials")
+
+
+@pytest.mark.parametrize("level", [2, 3])          # 320 triangles: raw in the file; 1280: behind upstream's 1000-triangle threshold -> QuickLZ block
+def test_cache_written_on_import_and_preferred_afterwards(level, tmp_path):
+    obj = scenes._write_mesh(str(tmp_path), "ico", scenes._icosphere(level, 1.5), [((0.8, 0.6, 0.4), None), ((0.2, 0.9, 0.4), None)])
+    clm = obj[:-4] + ".clm"
+    with driver.Session(64, 48, host_only=True) as s:
+        s.h.crth_prepare_meshes()
+        s.h.crth_import_mesh(obj.encode())
+        assert s.h.crth_last_error() == 0 and os.path.exists(clm)
+        first = _lib.as_array(s.h.crth_triangles(), s.h.crth_num_triangles(), _lib.TRI_DTYPE).copy()
+        n_mat = s.h.crth_num_materials()
+    assert len(first) == 20 * 4 ** level
+    import struct
+    blob = open(clm, "rb").read()
+    version, nt, nm = struct.unpack_from("<Iii", blob, 0)
+    msz, = struct.unpack_from("<I", blob, 12 + 24 * nm)
+    body = len(blob) - (12 + 24 * nm + 4 + msz)
+    assert version == 0 and nt == len(first) and nm == 2
+    assert body == nt * 80 + (17 if nt >= 1000 else 0)                      # u64 size + 9-byte QuickLZ header only above the threshold
+    os.utime(clm, (os.path.getmtime(obj) + 5, os.path.getmtime(obj) + 5))
+    os.rename(obj, obj + ".hidden")                                          # only the cache can serve the import now
+    with driver.Session(64, 48, host_only=True) as s:
+        s.h.crth_prepare_meshes()
+        s.h.crth_import_mesh(obj.encode())
+        assert s.h.crth_last_error() == 0
+        again = _lib.as_array(s.h.crth_triangles(), s.h.crth_num_triangles(), _lib.TRI_DTYPE)
+        assert again.tobytes() == first.tobytes() and s.h.crth_num_materials() == n_mat
+    # a corrupt cache is ignored when the OBJ is there, an error when it is not
+    os.rename(obj + ".hidden", obj)
+    with open(clm, "r+b") as f:
+        f.seek(40); f.write(b"\xff" * 64)
+    os.utime(clm, (os.path.getmtime(obj) + 5, os.path.getmtime(obj) + 5))
+    with driver.Session(64, 48, host_only=True) as s:
+        s.h.crth_prepare_meshes()
+        s.h.crth_import_mesh(obj.encode())
+        assert s.h.crth_last_error() == 0
+        assert _lib.as_array(s.h.crth_triangles(), s.h.crth_num_triangles(), _lib.TRI_DTYPE).tobytes() == first.tobytes()
