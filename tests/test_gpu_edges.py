@@ -214,3 +214,31 @@ def test_frames_in_flight_match_synchronous_frames(nthreads):
         _, stc = orc2.trace(orc2.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
         assert s.counters() == stc
         assert np.array_equal(bits(s.read_output()), bits(ref1))
+
+
+def test_empty_inputs(nthreads):
+    """No instances: every ray misses and samples the skybox (kernel_main.cl:198 loops zero times); zero query rays; a
+    zero-byte upload; a frame of the minimum size."""
+    sc = scenes.get("tiny")
+    hip = _lib.hip()
+    with driver.Session(16, 16, device=0) as s:                       # the smallest frame the reference accepts (Renderer.cpp:200)
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        args, _, _ = s.trace_args()
+        fp = C.POINTER(C.c_float)
+        for n_inst in (0, 1, len(sc.instances)):
+            args.numMeshes = n_inst
+            orc.s.numInstances = n_inst
+            ref, st = orc.trace(orc.raygen(16, 16, iv, ip), pos, sc.sun_angle)
+            for flags in (8, 4, 8 | 32):
+                if flags & 32:
+                    ref, st = orc.trace(orc.raygen(16, 16, iv, ip), pos, sc.sun_angle, shadows=True)
+                assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), flags) == 0
+                assert np.array_equal(bits(s.read_output()), bits(ref)), (n_inst, flags)
+                if flags & 8:
+                    assert s.counters() == st
+            if n_inst == 0:
+                assert st["hits"] == 0 and st["misses"] == 256 and st["traversals"] == 0
+        assert hip.crt_query_hits(None, None, 0, 0, None) == 0
+        assert hip.crt_upload_triangles(None, 0, 0) == 0 and hip.crt_upload_instances(None, 0, 0) == 0
