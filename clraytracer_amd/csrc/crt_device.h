@@ -91,9 +91,15 @@ struct CrtStackT {
     }
 };
 typedef CrtStackT<CRT_STACK_DEPTH> CrtStack;       // every slot in LDS
+#ifndef CRT_SPLIT_BETA
+#define CRT_SPLIT_BETA 1.0f
+#endif
+#ifndef CRT_SPLIT_BETA_ASYNC
+#define CRT_SPLIT_BETA_ASYNC 2.0f
+#endif
 #define CRT_MAX_SPLIT 96   // per XCD and frame: heaviest tiles traced as four 4x4-pixel waves instead of one 8x8 wave
 #ifndef CRT_MAX_SPLIT_PIPELINED
-#define CRT_MAX_SPLIT_PIPELINED 4   // with frames in flight the tail is hidden by the next frame: split only the very heaviest
+#define CRT_MAX_SPLIT_PIPELINED 8   // with frames in flight the tail is hidden by the next frame: split only the very heaviest
 #endif
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 

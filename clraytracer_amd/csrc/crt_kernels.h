@@ -52,7 +52,7 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
 // interleave row by row, which keeps them equally loaded when geometry is concentrated in one part
 // of the frame (a contiguous slab per XCD left most XCDs idle: ~1.2 resident waves/SIMD measured).
 // `slotOut` receives this workgroup's index into the per-tile cost array (or -1).
-__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, int* slotOut = nullptr)
+__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, int* slotOut = nullptr, bool* quadrantOut = nullptr)
 {
     const int b = blockIdx.x;
     const int xcd = b & 7;
@@ -67,6 +67,7 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
         const uint32_t e = F.order[xcd * F.listCap + slot];
         slot = (int)(e & 0x0FFFFFFFu);
         if (e & 0x80000000u) quadrant = (int)((e >> 28) & 3u);
+        if (quadrantOut) *quadrantOut = (e & 0x80000000u) != 0;
     } else if (slot >= F.slotsPerXcd) { if (slotOut) *slotOut = -1; return false; }
     if (slotOut) *slotOut = xcd * F.slotsPerXcd + slot;
     const int round = slot / F.tilesX;
@@ -85,22 +86,30 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
 }
 
 // Builds the next frame's launch lists: one workgroup per XCD, counting sort of that XCD's tiles by this frame's
-// cost, descending (1024 linear bins up to the list's maximum). The tiles that cost at least half the maximum
-// (at most CRT_MAX_SPLIT) are emitted as four quadrant entries each and come first.
+// cost, descending (1024 linear bins up to the list's maximum). A tile is traced by four quadrant waves instead of one
+// when its wave alone would run longer than `splitFactor` x (the XCD's total cost): with splitFactor = beta / (wave slots
+// of the XCD) that is "longer than beta times the time the XCD needs for the whole frame" -- only then does its serial
+// chain, not the throughput, decide when the frame ends. (A fixed "more than half the maximum, at most 96" rule
+// over-split large frames: 1920x1080 ran 16 % slower with 96 than with 4 splits per XCD, while one rank's eighth of
+// a 3840x2160 frame wanted them.) At most maxSplit tiles per XCD; they come first in the list.
 __global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
-                                                       uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap, uint32_t maxSplit)
+                                                       uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap, uint32_t maxSplit,
+                                                       float splitFactor)
 {
     __shared__ uint32_t s_bins[1024];
     __shared__ uint32_t s_max, s_nSplit;
+    __shared__ float s_sum;
     const int x = blockIdx.x, tid = threadIdx.x;
     const uint32_t* c = cost + (size_t)x * slotsPerXcd;
     uint32_t* o = order + (size_t)x * listCap;
     s_bins[tid] = 0;
-    if (tid == 0) s_max = 1;
+    if (tid == 0) { s_max = 1; s_sum = 0.0f; }
     __syncthreads();
-    uint32_t m = 0;
-    for (int i = tid; i < slotsPerXcd; i += 1024) m = c[i] > m ? c[i] : m;
+    uint32_t m = 0; float sum = 0.0f;
+    for (int i = tid; i < slotsPerXcd; i += 1024) { m = c[i] > m ? c[i] : m; sum += (float)c[i]; }
     atomicMax(&s_max, m);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if ((tid & 63) == 0) atomicAdd(&s_sum, sum);
     __syncthreads();
     const float scale = 1023.0f / (float)s_max;
     for (int i = tid; i < slotsPerXcd; i += 1024) {
@@ -120,12 +129,16 @@ __global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ 
         uint32_t wbase = 0;
         for (int w = 0; w < (tid >> 6); ++w) wbase += s_wave[w];
         s_bins[tid] = wbase + incl - n;
-        if (tid == 511) {
-            // bins 0..511 hold cost > max/2; a frame of near-equal tiles (nothing stands out) splits nothing
-            const uint32_t heavy = wbase + incl;
-            s_nSplit = (heavy * 8u > (uint32_t)slotsPerXcd) ? 0u : (heavy < maxSplit ? heavy : maxSplit);
-            listLen[x] = (uint32_t)slotsPerXcd + 3u * s_nSplit;
-        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // tiles in the bins above the threshold: s_bins[b] = number of tiles in bins 0..b-1 (heavier than bin b)
+        const float thr = splitFactor * s_sum;
+        int b = 1023 - (int)(thr * scale);
+        b = b < 0 ? 0 : (b > 1023 ? 1023 : b);
+        const uint32_t heavy = s_bins[b];
+        s_nSplit = heavy < maxSplit ? heavy : maxSplit;
+        listLen[x] = (uint32_t)slotsPerXcd + 3u * s_nSplit;
     }
     __syncthreads();
     const uint32_t nSplit = s_nSplit;
@@ -168,8 +181,9 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
     unsigned long long t0rt = 0, t0c = 0;
     if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
     int px, py, costSlot = -1;
+    bool isQuadrant = false;
     const unsigned long long tc0 = F.cost ? __builtin_amdgcn_s_memtime() : 0ull;
-    const bool active = lane_pixel(F, px, py, &costSlot);
+    const bool active = lane_pixel(F, px, py, &costSlot, &isQuadrant);
     if (active) {
         PathState ps;
         ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
@@ -196,8 +210,11 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
     }
     if (F.cost && costSlot >= 0) {      // per-tile cost of this frame (wave-uniform value, one store)
-        const unsigned long long dt = __builtin_amdgcn_s_memtime() - tc0;
-        if ((threadIdx.x & 63) == 0) atomicAdd(&F.cost[costSlot], dt > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)dt);   // the four waves of a split tile add up
+        // the four quadrant waves of a split tile each add half their cycles: about what the tile would take as one wave
+        // (a quadrant wave runs ~0.6x as long as the whole tile's), so a split tile neither sticks nor flips every frame
+        unsigned long long dt = __builtin_amdgcn_s_memtime() - tc0;
+        if (isQuadrant) dt >>= 1;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&F.cost[costSlot], dt > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)dt);
     }
     if (COUNT) flush_counters(lc, counters);
     if (STAMP) {

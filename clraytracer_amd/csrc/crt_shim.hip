@@ -64,6 +64,7 @@ struct State {
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
     int forceWide = -1;   // CRT_WIDE=0/1: force the megakernel flavour (tests); default: chosen per frame
     int feedback = 1; int maxSplit = CRT_MAX_SPLIT, maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED;
+    float splitBeta = CRT_SPLIT_BETA, splitBetaAsync = CRT_SPLIT_BETA_ASYNC;   // split a tile whose wave would run longer than beta x the XCD's time for the frame
     int ldsTiles = 0; uint32_t* listNext = nullptr;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
@@ -361,6 +362,8 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.listNext, 8 * sizeof(uint32_t)));
     g.numCUs = prop.multiProcessorCount;
     { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); g.wavefront = (e && strcmp(e, "wavefront") == 0); g.ldsTiles = (e && strcmp(e, "lds") == 0); }  // default: tile kernel (faster)
+    { const char* e = getenv("CRT_SPLIT_BETA"); g.splitBeta = e ? (float)atof(e) : CRT_SPLIT_BETA; }
+    { const char* e = getenv("CRT_SPLIT_BETA_ASYNC"); g.splitBetaAsync = e ? (float)atof(e) : CRT_SPLIT_BETA_ASYNC; }
     { const char* e = getenv("CRT_SPLIT");               // tuning knob: cap on quadrant-split tiles per XCD (both modes)
       if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
       else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
@@ -714,7 +717,8 @@ static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool
         crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, fs.stream>>>(fs.order, fs.len, F.slotsPerXcd, F.listCap);
         fs.orderSlots = F.slotsPerXcd; memcpy(fs.orderKey, key, sizeof key);
     } else {
-        crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit));
+        crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit),
+                                                     (pipelined ? g.splitBetaAsync : g.splitBeta) / (float)((g.numCUs / 8) * 4 * CRT_WAVES_PER_SIMD));
     }
     HIPCHK(hipGetLastError());
     F.order = fs.order; F.listLen = fs.len; F.cost = fs.cost;
