@@ -52,7 +52,7 @@
 //    wave occupies (XCC, SE, SH, CU, SIMD, wave slot from HW_ID / XCC_ID): waves resident at the same time never
 //    share an entry, whatever kernel or stream they belong to, and an entry is always written (push) before it is
 //    read (pop) within one traversal, so the area needs no initialisation. Used for frames in flight, where
-//    throughput decides: +6 % there, -9 % on a synchronous frame (a few spills in the hot loop).
+//    throughput decides: +6 % there, -1 % on a synchronous frame (a few spills outside the inner-node loop).
 // (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load.)
 typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
 #ifndef CRT_LDS_SLOTS_WIDE
