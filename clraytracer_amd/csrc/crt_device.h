@@ -92,7 +92,7 @@ struct CrtStackT {
 };
 typedef CrtStackT<CRT_STACK_DEPTH> CrtStack;       // every slot in LDS
 #ifndef CRT_SPLIT_BETA
-#define CRT_SPLIT_BETA 1.0f
+#define CRT_SPLIT_BETA 1.2f
 #endif
 #ifndef CRT_SPLIT_BETA_ASYNC
 #define CRT_SPLIT_BETA_ASYNC 2.0f
