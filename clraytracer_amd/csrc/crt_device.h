@@ -73,7 +73,7 @@ __device__ __forceinline__ uint32_t* crt_overflow_slot(uint32_t* base, int k)
 }
 template <int LDS_SLOTS>
 struct CrtStackT {
-    static_assert(LDS_SLOTS == CRT_STACK_DEPTH || LDS_SLOTS == CRT_LDS_SLOTS_WIDE, "the overflow area is sized for these two");
+    static_assert(LDS_SLOTS <= CRT_STACK_DEPTH && LDS_SLOTS >= CRT_LDS_SLOTS_WIDE, "the overflow area holds CRT_STACK_DEPTH - CRT_LDS_SLOTS_WIDE slots per wave");
     static constexpr int kLdsSlots = LDS_SLOTS;
     crt_lds_u32_ptr lds;     // this lane's slot 0
     uint32_t* ovf;           // base of the overflow area (wave-uniform); unused when every slot is in LDS
@@ -90,6 +90,9 @@ struct CrtStackT {
         return *crt_overflow_slot(ovf, s - LDS_SLOTS);
     }
 };
+#ifndef CRT_LDS_SLOTS_NARROW
+#define CRT_LDS_SLOTS_NARROW CRT_STACK_DEPTH
+#endif
 typedef CrtStackT<CRT_STACK_DEPTH> CrtStack;       // every slot in LDS
 #ifndef CRT_SPLIT_BETA
 #define CRT_SPLIT_BETA 1.2f

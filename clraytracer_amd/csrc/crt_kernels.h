@@ -174,7 +174,7 @@ template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool WIDE = false
 __global__ __launch_bounds__(CRT_BLOCK, WIDE ? CRT_WAVES_PER_SIMD_WIDE : CRT_WAVES_PER_SIMD)
 void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    typedef CrtStackT<WIDE ? CRT_LDS_SLOTS_WIDE : CRT_STACK_DEPTH> Stack;
+    typedef CrtStackT<WIDE ? CRT_LDS_SLOTS_WIDE : CRT_LDS_SLOTS_NARROW> Stack;
     __shared__ uint32_t s_stack[Stack::kLdsSlots * CRT_BLOCK];
     const Stack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
