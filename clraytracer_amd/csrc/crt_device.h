@@ -106,6 +106,13 @@ typedef CrtStackT<CRT_STACK_DEPTH> CrtStack;       // every slot in LDS
 #endif
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 
+// Node of the instance tree (TLAS): a world-space bounding sphere and two children; child bit 31 set = leaf, low bits =
+// instance index. Built on the host whenever instances are uploaded (crt_shim.hip, rebuild_instance_bounds).
+struct CrtTlasNode { float4 sphere; uint32_t left, right, pad0, pad1; };
+#define CRT_TLAS_LEAF 0x80000000u
+#define CRT_TLAS_MIN_INSTANCES 64      // with fewer instances the linear sphere loop of candidate_mask is cheaper
+#define CRT_TLAS_LIST 8                // candidates a lane can hold; a wave with a lane that needs more uses the chunked loop
+
 struct CrtDevScene {
     const float4* __restrict__ pairs;
     const float* __restrict__ triHot;
@@ -121,6 +128,10 @@ struct CrtDevScene {
     const uint32_t* __restrict__ texels;
     int numTexels;
     uint32_t numInstances;
+    const CrtTlasNode* __restrict__ tlas;    // bounding-sphere tree over the cullable instances (host-built), or null
+    uint32_t tlasNodes;                      // 0: no tree (few instances, or none cullable)
+    const uint32_t* __restrict__ alwaysList; // instances that are never culled (single-leaf meshes, unbounded), ascending
+    uint32_t numAlways;
 };
 
 struct CrtFrame {
@@ -377,6 +388,15 @@ struct Traversal {
     }
 };
 
+// The conservative ray/sphere rejection of candidate_mask for the instance tree (same arithmetic; any NaN -> not culled).
+__device__ __forceinline__ bool sphere_culls(const float4 bs, v3 o, v3 d, float dd)
+{
+    const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);
+    const float oc2 = dot3(oc, oc), b = dot3(oc, d);
+    const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2;           // 1 % on the radius + slack growing with distance
+    return (bs.w >= 0.0f) & ((oc2 * dd - b * b > r2 * dd) | ((b < 0.0f) & (oc2 > r2)));
+}
+
 // Conservative candidate mask for instances [base, base + cnt): bit k is cleared only when the ray provably misses
 // instance base+k's bounding sphere (any NaN -> candidate). A culled instance costs upstream exactly one pop and one
 // inner visit and changes nothing, which is what the counters record for it. Wave-uniform loop, scalar loads.
@@ -397,6 +417,58 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
     return cand;
 }
 
+// Candidate instances of one ray from the instance tree: up to CRT_TLAS_LIST indices (16 bits each, unordered, 0xFFFF =
+// empty) in four registers; returns false when the lane would need more. The traversal stack is idle at this point
+// and serves as the tree stack. Scenes with hundreds of instances (upstream allows 401 and loops over all of them for
+// every ray, kernel_main.cl:198) spend their time here otherwise: 401 instances, 1920x1080: 1.12 ms -> see DESIGN.md.
+struct CandidateList { uint32_t w[CRT_TLAS_LIST / 2]; uint32_t n; };
+__device__ __forceinline__ bool candidate_list_add(CandidateList& L, uint32_t idx)
+{
+    if (L.n >= (uint32_t)CRT_TLAS_LIST) return false;
+    const uint32_t sh = (L.n & 1u) * 16u, m = ~(0xFFFFu << sh), v = idx << sh;
+#pragma unroll
+    for (int k = 0; k < CRT_TLAS_LIST / 2; ++k) if ((L.n >> 1) == (uint32_t)k) L.w[k] = (L.w[k] & m) | v;
+    L.n++;
+    return true;
+}
+// smallest candidate index greater than `after` (after = -1 for the first), or 0xFFFF
+__device__ __forceinline__ uint32_t candidate_list_next(const CandidateList& L, int after)
+{
+    uint32_t best = 0xFFFFu;
+#pragma unroll
+    for (int k = 0; k < CRT_TLAS_LIST / 2; ++k) {
+        const uint32_t lo = L.w[k] & 0xFFFFu, hi = L.w[k] >> 16;
+        if ((int)lo > after && lo < best) best = lo;
+        if ((int)hi > after && hi < best) best = hi;
+    }
+    return best;
+}
+template <class Stack>
+__device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d, const Stack& stack, CandidateList& L)
+{
+#pragma unroll
+    for (int k = 0; k < CRT_TLAS_LIST / 2; ++k) L.w[k] = 0xFFFFFFFFu;
+    L.n = 0;
+    bool ok = true;
+    for (uint32_t k = 0; k < S.numAlways; ++k) { const uint32_t i = S.alwaysList[k]; if (i < S.numInstances) ok = candidate_list_add(L, i) && ok; }
+    if (S.tlasNodes == 0) return ok;
+    const float dd = dot3(d, d);
+    uint32_t node = 0; int sp = 0;
+    for (;;) {
+        const CrtTlasNode nd = S.tlas[node];
+        bool descend = false;
+        if (!sphere_culls(nd.sphere, o, d, dd)) {
+            // children: a leaf child is tested through its own sphere when it is popped as a one-node subtree
+            if (nd.left & CRT_TLAS_LEAF) {
+                const uint32_t i = nd.left & 0xFFFFu;             // a leaf NODE: left = leaf | instance, right unused
+                if (i < S.numInstances) ok = candidate_list_add(L, i) && ok;
+            } else { stack.write(sp, nd.right); sp++; node = nd.left; descend = true; }
+        }
+        if (!descend) { if (sp == 0) break; --sp; node = stack.read(sp); }
+    }
+    return ok;
+}
+
 // Packets with at most this many lanes still working advance every lane through every step kind each trip
 // (latency of the longest ray matters, issue slots do not); larger packets vote for one step kind per trip.
 #ifndef CRT_SMALL_PACKET
@@ -413,7 +485,7 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
 // ANYHIT (shadow rays, CRT_RENDER_SHADOWS): a lane stops at the first triangle that passes -- inside the leaf, and
 // for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
 // first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
-template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader, bool ANYHIT = false, class Stack = CrtStack>
+template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader, bool ANYHIT = false, class Stack = CrtStack, bool TLAS = false>
 __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, const Stack& stack, LaneCounters& lc,
                                                const PairLoader& loadPair = PairLoader())
 {
@@ -421,6 +493,44 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
     c.hit.t = 0.0f; c.hit.u = 0.0f; c.hit.v = 0.0f; c.hit.tri = 0;
     Traversal<COUNT> T; T.reset();
+
+    if (TLAS) {
+        // Many instances: every lane collects its (few) candidates from the instance tree and walks them in ascending
+        // order -- the same instances, in the same order, as the chunked loop below would. A wave in which some lane
+        // has more than CRT_TLAS_LIST candidates takes the chunked loop instead.
+        CandidateList L;
+        const bool fits = tlas_candidates(S, o, d, stack, L);
+        if (__ballot(!fits) == 0) {
+            int prev = -1;                                        // last instance entered (ANYHIT + COUNT: culled ones in between)
+            if (COUNT && !ANYHIT) { const uint32_t culled = S.numInstances - L.n; lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
+            bool done = false;
+            for (;;) {
+                const bool wEnter = !done && !T.active;
+                const bool wInner = !done && T.at_inner();
+                const bool wLeaf = !done && T.at_leaf();
+                const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
+                if (nE + nI + nL == 0) break;
+                const bool all = (nE + nI + nL) <= (uint32_t)CRT_SMALL_PACKET;
+                const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
+                if (all || (!runI && !runL)) {
+                    if (wEnter) {
+                        const uint32_t k = (ANYHIT && c.anyHit) ? 0xFFFFu : candidate_list_next(L, prev);
+                        if (k == 0xFFFFu) {
+                            done = true;
+                            if (COUNT && ANYHIT && !c.anyHit) { const uint32_t n = S.numInstances - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; }
+                        } else {
+                            if (COUNT && ANYHIT) { const uint32_t n = k - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; }
+                            prev = (int)k;
+                            T.enter(S, k, o, d, c.distance, lc);
+                        }
+                    }
+                }
+                if (all || runI) { if (!done && T.at_inner()) T.inner(S, loadPair, stack, c, lc); }
+                if (all || runL) { if (!done && T.at_leaf()) T.template leaf<ANYHIT>(S, stack, c, lc); }
+            }
+            return c;
+        }
+    }
 
     for (uint32_t base = 0; base < S.numInstances; base += 64) {
         const uint32_t cnt = (S.numInstances - base) < 64u ? (S.numInstances - base) : 64u;

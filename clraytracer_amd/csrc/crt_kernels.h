@@ -170,7 +170,8 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
 // where it is observable: at bounce 0 (the energy after bounce 1 is never read) and when n.l > 0 (otherwise the
 // product is 0 whatever the shadow factor).
 // WIDE: the 6-waves/SIMD flavour (25 LDS stack slots + overflow area, crt_device.h) used for frames in flight.
-template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool WIDE = false>
+// TLAS: candidates come from the instance tree instead of the linear sphere loop (scenes with many instances).
+template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool WIDE = false, bool TLAS = false>
 __global__ __launch_bounds__(CRT_BLOCK, WIDE ? CRT_WAVES_PER_SIMD_WIDE : CRT_WAVES_PER_SIMD)
 void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
@@ -192,7 +193,7 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
         ps.energy = 1.0f;
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT, STAMP, GlobalPairLoader, false, Stack>(S, ps.o, ps.d, stack, lc);
+            Closest c = closest_hit<COUNT, STAMP, GlobalPairLoader, false, Stack, TLAS>(S, ps.o, ps.d, stack, lc);
             float ndl = 0.0f;
             bool cont = shade_bounce<SHADOW>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
@@ -201,7 +202,7 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
                 float shadow = 1.0f;
                 if (bounce == 0 && ndl > 0.0f) {
                     if (COUNT) { lc.rays++; lc.shadowRays++; }
-                    const Closest sc = closest_hit<COUNT, false, GlobalPairLoader, true, Stack>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc);
+                    const Closest sc = closest_hit<COUNT, false, GlobalPairLoader, true, Stack, TLAS>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc);
                     if (sc.anyHit) { shadow = 0.0f; if (COUNT) lc.shadowHits++; }
                 }
                 ps.energy = ps.energy * specular_x(ndl, shadow);
@@ -370,6 +371,7 @@ __global__ void crt_pack_unorm8_kernel(const float4* __restrict__ img, uint32_t*
 }
 
 // closest-hit query over explicit rays (hit-record parity)
+template <bool TLAS>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
         v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
         v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
         lc.rays++;
-        Closest c = closest_hit<true>(S, o, d, stack, lc);
+        Closest c = closest_hit<true, false, GlobalPairLoader, false, CrtStack, TLAS>(S, o, d, stack, lc);
         CrtRayHit h;
         if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
         else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }

@@ -14,6 +14,7 @@
 #include "crt_relayout.h"
 #include "crt_bvh_build.h"
 #include <vector>
+#include <algorithm>
 #include <utility>
 
 // ------------------------------------------------------------------------------------------------
@@ -57,12 +58,14 @@ struct State {
     uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr; uint32_t* stackOverflow = nullptr;
     CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
     float4* instBounds = nullptr; CrtDevInstance* devInstances = nullptr; uint32_t* hotSlot = nullptr;
+    CrtTlasNode* tlas = nullptr; uint32_t* alwaysList = nullptr; uint32_t tlasNodes = 0, numAlways = 0;   // instance tree (rebuild_instance_bounds)
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
     float* rays = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
     int forceWide = -1;   // CRT_WIDE=0/1: force the megakernel flavour (tests); default: chosen per frame
+    int forceTlas = -1;   // CRT_TLAS=0/1: force the linear / tree candidate search (tests); default: by instance count
     int feedback = 1; int maxSplit = CRT_MAX_SPLIT, maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED;
     float splitBeta = CRT_SPLIT_BETA, splitBetaAsync = CRT_SPLIT_BETA_ASYNC;   // split a tile whose wave would run longer than beta x the XCD's time for the frame
     int ldsTiles = 0; uint32_t* listNext = nullptr;
@@ -136,6 +139,7 @@ void fill_scene(CrtDevScene& S, uint32_t numInstances)
     S.numTexels = (int)((g.texelBytesHigh + 2) / 3);
     if (S.numTexels < 1) S.numTexels = 1;
     S.numInstances = numInstances;
+    S.tlas = g.tlas; S.tlasNodes = g.tlasNodes; S.alwaysList = g.alwaysList; S.numAlways = g.numAlways;
 }
 
 int alloc_frame_buffers(int w, int h)
@@ -243,6 +247,53 @@ int rebuild_instance_bounds()
         bounds[i] = b;
     }
     HIPCHK(hipMemcpyAsync(g.instBounds, bounds, sizeof bounds, hipMemcpyHostToDevice, g.stream));
+    // Instance tree for scenes with many instances (closest_hit<..., TLAS>): median-split binary tree over the cullable
+    // instances' spheres, node sphere = centre and half diagonal of the box around its children's spheres. Instances
+    // that are never culled go to a separate ascending list.
+    {
+        static CrtTlasNode nodes[2 * CRT_MAX_INSTANCES];
+        static uint32_t always[CRT_MAX_INSTANCES];
+        uint32_t nAlways = 0, nLeaves = 0, nNodes = 0;
+        uint32_t leaves[CRT_MAX_INSTANCES];
+        // only instances that were uploaded; a frame that asks for more (never-uploaded, all-zero records) uses the linear loop
+        for (uint32_t i = 0; i < g.instHigh; ++i) { if (bounds[i].w < 0.0f) always[nAlways++] = i; else leaves[nLeaves++] = i; }
+        struct Range { uint32_t lo, hi, node; };
+        if (nLeaves) {
+            Range stack[64]; int sp = 0;
+            stack[sp++] = Range{ 0, nLeaves, nNodes++ };
+            while (sp) {
+                const Range r = stack[--sp];
+                double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 }, clo[3] = { 1e300, 1e300, 1e300 }, chi[3] = { -1e300, -1e300, -1e300 };
+                for (uint32_t k = r.lo; k < r.hi; ++k) {
+                    const float4 b = bounds[leaves[k]]; const double c[3] = { b.x, b.y, b.z };
+                    for (int a = 0; a < 3; ++a) {
+                        if (c[a] - b.w < lo[a]) lo[a] = c[a] - b.w;
+                        if (c[a] + b.w > hi[a]) hi[a] = c[a] + b.w;
+                        if (c[a] < clo[a]) clo[a] = c[a];
+                        if (c[a] > chi[a]) chi[a] = c[a];
+                    }
+                }
+                CrtTlasNode& n = nodes[r.node];
+                n.pad0 = n.pad1 = 0;
+                if (r.hi - r.lo == 1) { n.sphere = bounds[leaves[r.lo]]; n.left = CRT_TLAS_LEAF | leaves[r.lo]; n.right = 0; continue; }
+                const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                n.sphere = make_float4((float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2])),
+                                       (float)(0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-5)));
+                int axis = 0;
+                if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+                if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+                const uint32_t mid = (r.lo + r.hi) / 2;
+                auto key = [&](uint32_t idx) { const float4 b = bounds[idx]; return axis == 0 ? b.x : (axis == 1 ? b.y : b.z); };
+                std::nth_element(leaves + r.lo, leaves + mid, leaves + r.hi, [&](uint32_t p, uint32_t q) { return key(p) < key(q) || (key(p) == key(q) && p < q); });
+                n.left = nNodes++; n.right = nNodes++;
+                stack[sp++] = Range{ mid, r.hi, n.right };
+                stack[sp++] = Range{ r.lo, mid, n.left };
+            }
+        }
+        if (nNodes) HIPCHK(hipMemcpyAsync(g.tlas, nodes, nNodes * sizeof(CrtTlasNode), hipMemcpyHostToDevice, g.stream));
+        if (nAlways) HIPCHK(hipMemcpyAsync(g.alwaysList, always, nAlways * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+        g.tlasNodes = nNodes; g.numAlways = nAlways;
+    }
     crt_relayout_instances<<<(CRT_MAX_INSTANCES + 255) / 256, 256, 0, g.stream>>>(g.instances, g.rootRefs, CRT_MAX_INSTANCES, g.devInstances);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -352,6 +403,8 @@ int crt_init(int device, int width, int height)
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
     HIPCHK(hipMalloc(&g.instBounds, CRT_MAX_INSTANCES * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.tlas, 2 * CRT_MAX_INSTANCES * sizeof(CrtTlasNode)));
+    HIPCHK(hipMalloc(&g.alwaysList, CRT_MAX_INSTANCES * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.devInstances, CRT_MAX_INSTANCES * sizeof(CrtDevInstance)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
@@ -367,6 +420,7 @@ int crt_init(int device, int width, int height)
     { const char* e = getenv("CRT_SPLIT");               // tuning knob: cap on quadrant-split tiles per XCD (both modes)
       if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
       else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
+    { const char* e = getenv("CRT_TLAS"); g.forceTlas = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     { const char* e = getenv("CRT_WIDE"); g.forceWide = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
@@ -393,7 +447,7 @@ int crt_shutdown(void)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     (void)sync_all();
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
+                     g.texels, g.instances, g.instBounds, g.tlas, g.alwaysList, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
     for (FrameSlot& fs : g.slot) { void* q[] = { fs.out, fs.order, fs.len, fs.cost }; for (void* p : q) if (p) (void)hipFree(p); }
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -786,7 +840,10 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         const bool wide = g.forceWide >= 0 ? g.forceWide != 0
                                            : ((flags & CRT_RENDER_ASYNC) != 0
                                               && 2 * tiles * (size_t)g.nSlots >= (size_t)13 * (size_t)g.numCUs * 4 * CRT_WAVES_PER_SIMD_WIDE);
-#define CRT_LAUNCH_TRACE(C_, S_, W_) crt_trace_kernel<C_, false, S_, W_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters)
+        // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
+        const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && g.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && g.tlasNodes > 0);
+#define CRT_LAUNCH_TRACE(C_, S_, W_) do { if (tlas) crt_trace_kernel<C_, false, S_, W_, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
+                                          else crt_trace_kernel<C_, false, S_, W_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
         if (count) { if (shadow) { if (wide) CRT_LAUNCH_TRACE(true, true, true); else CRT_LAUNCH_TRACE(true, true, false); }
                      else        { if (wide) CRT_LAUNCH_TRACE(true, false, true); else CRT_LAUNCH_TRACE(true, false, false); } }
         else       { if (shadow) { if (wide) CRT_LAUNCH_TRACE(false, true, true); else CRT_LAUNCH_TRACE(false, true, false); }
@@ -888,7 +945,9 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     HIPCHK(hipMemcpyAsync(dD, dirs, rayBytes, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), g.stream));
     CrtDevScene S; fill_scene(S, numInstances);
-    crt_query_kernel<<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
+    const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && g.tlasNodes > 0 && numInstances <= g.instHigh) : (numInstances > CRT_TLAS_MIN_INSTANCES && numInstances <= g.instHigh && g.tlasNodes > 0);
+    if (tlas) crt_query_kernel<true><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
+    else crt_query_kernel<false><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dH, sizeof(CrtRayHit) * (size_t)n, hipMemcpyDeviceToHost, g.stream));
     unsigned long long c[CRT_NUM_COUNTERS];

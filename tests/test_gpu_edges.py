@@ -44,7 +44,15 @@ def write_mesh(tmp, name, mesh):
     return scenes._write_mesh(str(tmp), name, mesh, [((0.8, 0.6, 0.4), None)])
 
 
-def test_max_instances_single_leaf_and_big_leaf(tmp_path, nthreads):
+@pytest.fixture(params=["0", "1"], ids=["linear", "tree"])
+def candidate_search(request, monkeypatch):
+    """CRT_TLAS (read by crt_init) forces how a ray finds its candidate instances: the linear sphere loop or the instance
+    tree, which is otherwise used above 64 instances."""
+    monkeypatch.setenv("CRT_TLAS", request.param)
+    return request.param
+
+
+def test_max_instances_single_leaf_and_big_leaf(tmp_path, candidate_search, nthreads):
     # mesh 0: one triangle (root is a leaf: tested with no box test, never culled)
     # mesh 1: 200 identical triangles -> SAH cannot split -> one leaf with 200 triangles (bigLeaf escape)
     # mesh 2: a small icosphere (ordinary tree)
@@ -223,11 +231,13 @@ def test_empty_inputs(nthreads):
     hip = _lib.hip()
     with driver.Session(16, 16, device=0) as s:                       # the smallest frame the reference accepts (Renderer.cpp:200)
         s.load_scene(sc)
-        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        a = dict(s.arenas())
+        a["instances"] = np.concatenate([a["instances"], np.zeros(5, _lib.INSTANCE_DTYPE)])   # what the device pool holds past the uploads
+        orc = oracle_lib.Oracle(a, nthreads=nthreads)
         iv, ip, pos = s.camera()
         args, _, _ = s.trace_args()
         fp = C.POINTER(C.c_float)
-        for n_inst in (0, 1, len(sc.instances)):
+        for n_inst in (0, 1, len(sc.instances), len(sc.instances) + 5):    # + 5: instances that were never uploaded (all-zero records)
             args.numMeshes = n_inst
             orc.s.numInstances = n_inst
             ref, st = orc.trace(orc.raygen(16, 16, iv, ip), pos, sc.sun_angle)
