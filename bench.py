@@ -268,7 +268,7 @@ def main():
                           "device_time_per_frame_max_over_ranks": round(kernel_ms_max, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "crt_trace_kernel<false, false, true>" if args.shadows else "crt_trace_kernel<false, false, false>", "algorithmic_bytes_per_launch": int(my_bytes),
+                         "kernel": "crt_trace_kernel<COUNT=false, STAMP=false, SHADOW=%s, WIDE=per frame, TLAS=false>" % ("true" if args.shadows else "false"), "algorithmic_bytes_per_launch": int(my_bytes),
                          "launch_duration_ms": round(launch_ms, 4), "launches_in_flight": flight,
                          "achieved_per_launch": round(my_bytes / (launch_ms * 1e-3) / 1e9, 2),
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
