@@ -80,8 +80,7 @@ size_t MeshCache_QlzDecompress(const unsigned char* src, size_t srcLen, unsigned
             hash_upto(start);
             hashed = d;                                        // the inside of a match is never hashed
         } else if (d < lastMatchStart) {                       // 1..4 literals
-            static const unsigned runs[16] = { 4, 0, 1, 0, 2, 0, 1, 0, 3, 0, 1, 0, 2, 0, 1, 0 };
-            const unsigned k = runs[cword & 0xf];
+            const unsigned k = (unsigned)__builtin_ctz((cword & 0xfu) | 0x10u);   // literal flags (zeros) at the bottom of the nibble: 0..4
             if (d + 4 > size) return 0;
             std::memcpy(dst + d, s, 4);                        // only k of them count; the rest is overwritten
             cword >>= k; d += k; s += k;
