@@ -79,7 +79,9 @@ __global__ void crt_bvh_init_roots(CrtBuildNode* __restrict__ nodes, const uint3
 // bulk of the deep levels: the builder splits down to one or two triangles per leaf) get one THREAD each that replays
 // upstream's sequential code literally (crt_bvh_tiny).
 #define CRT_BVH_SMALL 2048
+#ifndef CRT_BVH_TINY
 #define CRT_BVH_TINY 8
+#endif
 enum { CRT_BVH_CLASS_BIG = 0, CRT_BVH_CLASS_MID = 1, CRT_BVH_CLASS_TINY = 2 };
 __host__ __device__ __forceinline__ int bvh_class(uint32_t count) { return count > CRT_BVH_SMALL ? CRT_BVH_CLASS_BIG : (count > CRT_BVH_TINY ? CRT_BVH_CLASS_MID : CRT_BVH_CLASS_TINY); }
 // Children are appended to the node array and to next level's lists with ONE 64-bit atomic per splitting node (per wave
@@ -448,21 +450,22 @@ __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* _
         const float c = bestAxis == 0 ? cen[i][0] : (bestAxis == 1 ? cen[i][1] : cen[i][2]);
         if ((uint32_t)i < n && c < splitPos) left |= 1u << i;
     }
-    uint32_t perm = 0x76543210u;
+    static_assert(CRT_BVH_TINY <= 16, "the permutation is packed four bits per entry into 64 bits");
+    unsigned long long perm = 0xFEDCBA9876543210ull;
     int i = 0, j = (live && !isLeaf) ? (int)n - 1 : -1;
     while (i <= j) {
-        const uint32_t pi = (perm >> (4 * i)) & 15u;
+        const unsigned long long pi = (perm >> (4 * i)) & 15ull;
         if ((left >> pi) & 1u) i++;
         else {
-            const uint32_t pj = (perm >> (4 * j)) & 15u;
-            perm = (perm & ~((15u << (4 * i)) | (15u << (4 * j)))) | (pj << (4 * i)) | (pi << (4 * j));
+            const unsigned long long pj = (perm >> (4 * j)) & 15ull;
+            perm = (perm & ~((15ull << (4 * i)) | (15ull << (4 * j)))) | (pj << (4 * i)) | (pi << (4 * j));
             j--;
         }
     }
     const uint32_t L = (uint32_t)i;
     const bool tried = live && !isLeaf, split = tried && L != 0 && L != n;
     if (tried) {
-        for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(dst, (size_t)first + x, src, (size_t)first + ((perm >> (4 * x)) & 15u));
+        for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(dst, (size_t)first + x, src, (size_t)first + (size_t)((perm >> (4 * x)) & 15ull));
         if (!split) {                                          // BVH.cpp:194: stays a leaf, triangles stay permuted -> both buffers
             node.state = 3u;
             for (uint32_t x = 0; x < n; ++x) bvh_copy_tri(src, (size_t)first + x, dst, (size_t)first + x);
