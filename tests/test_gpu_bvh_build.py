@@ -156,3 +156,20 @@ def test_mirrored_resource_manager_with_device_build(name):
         s.render_raw(0)
         assert np.array_equal(bits(s.read_output()), bits(ref))
         print(f"{name}: load_scene {t_host * 1e3:.0f} ms with the host BuildBVH, {t_dev * 1e3:.0f} ms with crt_build_bvh")
+
+
+def test_build_errors_are_codes(session):
+    hip = _lib.hip()
+    tris = special_tris("random", 300, 41)
+    assert hip.crt_upload_triangles(tris.ctypes.data, 0, tris.nbytes) == 0
+    used = C.c_uint32(0)
+    ok = np.array([300], np.uint32); zero = np.array([100, 0, 200], np.uint32); big = np.array([10 ** 7], np.uint32)
+    assert hip.crt_build_bvh(0, None, 1, 0, 0, C.byref(used)) == -2
+    assert hip.crt_build_bvh(0, zero.ctypes.data, 3, 0, 0, C.byref(used)) == -2            # an empty mesh has no root leaf
+    assert hip.crt_build_bvh(0, big.ctypes.data, 1, 0, 0, C.byref(used)) == -2             # triangles that were never uploaded
+    assert hip.crt_build_bvh(0, ok.ctypes.data, 1, 0, 128, C.byref(used)) == -3            # mesh table is 128 entries
+    assert hip.crt_build_bvh(0, ok.ctypes.data, 1, 2400000 - 10, 0, C.byref(used)) == -3    # node pool
+    assert hip.crt_build_bvh(0, ok.ctypes.data, 1, 0, 0, None) == 0                         # nodesUsedOut is optional
+    buf = np.zeros(64, np.uint8)
+    assert hip.crt_download_triangles(buf.ctypes.data, 0, 81) == -2 and hip.crt_download_bvh_nodes(buf.ctypes.data, 0, 33) == -2
+    assert hip.crt_download_bvh_roots(buf.ctypes.data, 127, 2) == -3 and hip.crt_download_triangles(None, 0, 80) == -2
