@@ -150,3 +150,32 @@ def test_scene_load_bookkeeping():
         assert inst["materialStart"].tolist() == [1, 3, 1]
         for k, i in enumerate(sc.instances):
             assert np.allclose(i.matrix.astype(np.float64) @ inst["inv"][k].astype(np.float64), np.eye(4), atol=1e-5)
+
+
+def test_triangle_arena_capacity_is_an_error_not_an_overrun(tmp_path):
+    """MAX_TRIANGLES (1.2 M, ResourceManager.cpp:34) bounds the host arena: importing past it must fail with a code while
+    parsing (upstream would write past the arena first and exit later), from the OBJ and from a `.clm` cache alike."""
+    import numpy as np
+    from clraytracer_amd import _lib, driver, scenes
+    big = scenes._icosphere(7, 1.0)                       # 327,680 triangles
+    obj = scenes._write_mesh(str(tmp_path), "big", big, [((0.5, 0.5, 0.5), None)])
+    with driver.Session(64, 48, host_only=True) as s:
+        h = s.h
+        h.crth_prepare_meshes()
+        for k in range(3):                                # 983,040 triangles in
+            h.crth_import_mesh(obj.encode())
+            assert h.crth_last_error() == 0, k
+        assert h.crth_num_triangles() == 3 * 327680
+        h.crth_import_mesh(obj.encode())                  # the fourth would end at 1,310,720 > 1,200,000 (served from the .clm cache)
+        assert h.crth_last_error() == -3 or h.crth_last_error() == -2
+        assert h.crth_num_triangles() == 3 * 327680 and h.crth_num_meshes() == 3
+    os.remove(obj[:-4] + ".clm")
+    with driver.Session(64, 48, host_only=True) as s:
+        h = s.h
+        h.crth_set_mesh_cache(0)                          # the same through the OBJ parser
+        h.crth_prepare_meshes()
+        for k in range(3):
+            h.crth_import_mesh(obj.encode())
+        h.crth_import_mesh(obj.encode())
+        assert h.crth_last_error() in (-2, -3) and h.crth_num_meshes() == 3
+        h.crth_set_mesh_cache(1)
