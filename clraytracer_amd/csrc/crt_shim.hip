@@ -37,6 +37,7 @@ struct FrameSlot {
     float4* out = nullptr;
     uint32_t* order = nullptr; uint32_t* len = nullptr; uint32_t* cost = nullptr;   // feedback launch lists
     size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 };
+    bool listsReady = false;                   // the lists for the next frame were already sorted at the end of the last one
 };
 
 struct State {
@@ -748,9 +749,10 @@ int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count)
 }
 
 // Feedback launch lists for the megakernel (lane_pixel / crt_order_kernel). Buffers follow the frame geometry; a
-// change of geometry resets to the identity order. Every frame starts by turning the previous frame's per-tile
-// costs into this frame's lists (and zeroing the costs), so the sort is inside the frame but outside the Trace
-// event pair.
+// change of geometry resets to the identity order. The previous frame's per-tile costs are turned into this frame's
+// lists (and the costs zeroed) by a sort that is queued right AFTER the previous frame's last kernel and its end
+// event (sort_for_next_frame), so it runs while the host is between two crt_render calls and is off the frame's
+// critical path (it used to open every frame: 10 us + a launch gap of a 0.5 ms synchronous frame).
 static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool pipelined)
 {
     const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
@@ -770,13 +772,25 @@ static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool
         HIPCHK(hipMemsetAsync(fs.cost, 0, sizeof(uint32_t) * need, fs.stream));
         crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, fs.stream>>>(fs.order, fs.len, F.slotsPerXcd, F.listCap);
         fs.orderSlots = F.slotsPerXcd; memcpy(fs.orderKey, key, sizeof key);
-    } else {
+    } else if (!fs.listsReady) {
         crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit),
                                                      (pipelined ? g.splitBetaAsync : g.splitBeta) / (float)((g.numCUs / 8) * 4 * CRT_WAVES_PER_SIMD));
     }
+    fs.listsReady = false;
     HIPCHK(hipGetLastError());
     F.order = fs.order; F.listLen = fs.len; F.cost = fs.cost;
     grid = 8u * (unsigned)F.listCap;
+    return CRT_OK;
+}
+
+// Queued behind a frame's last kernel: this frame's costs -> the next frame's lists (same geometry assumed; a change is
+// caught by the key in prepare_launch_lists, which then starts from the identity order again).
+static int sort_for_next_frame(const CrtFrame& F, FrameSlot& fs, bool pipelined)
+{
+    crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit),
+                                                 (pipelined ? g.splitBetaAsync : g.splitBeta) / (float)((g.numCUs / 8) * 4 * CRT_WAVES_PER_SIMD));
+    HIPCHK(hipGetLastError());
+    fs.listsReady = true;
     return CRT_OK;
 }
 
@@ -912,7 +926,11 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     }
     g.cur = slot;
     es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
-    if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipStreamSynchronize(fs.stream));   // the reference's clFinish (Renderer.cpp:367)
+    const bool sorted = F.order != nullptr && !g.ldsTiles;
+    if (sorted) { rc = sort_for_next_frame(F, fs, pipelined); if (rc) return rc; }
+    // the reference's clFinish (Renderer.cpp:367): wait for the frame's end event -- the sort for the next frame that is
+    // queued behind it needs no waiting for
+    if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipEventSynchronize(es.evPost ? es.ev[3] : es.ev[2]));
     return CRT_OK;
 }
 
