@@ -366,7 +366,7 @@ const char* crt_error_string(int code)
 
 const char* crt_device_name(void) { return g.deviceName; }
 
-int crt_init(int device, int width, int height)
+static int init_impl(int device, int width, int height)
 {
     if (g.initialized) return CRT_E_BAD_ARGUMENT;
     if (width < 16 || height < 16) return CRT_E_BAD_ARGUMENT;
@@ -443,10 +443,10 @@ int crt_init(int device, int width, int height)
     return crt_upload_texels(def, 0, 6);
 }
 
-int crt_shutdown(void)
+// frees everything State holds (also after a crt_init that failed half way) and resets it
+static void release_all()
 {
-    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    (void)sync_all();
+    for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.instances, g.instBounds, g.tlas, g.alwaysList, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
@@ -458,6 +458,20 @@ int crt_shutdown(void)
         if (fs.stream) (void)hipStreamDestroy(fs.stream);
     }
     g = State();
+}
+
+int crt_init(int device, int width, int height)
+{
+    if (g.initialized) return CRT_E_BAD_ARGUMENT;
+    const int rc = init_impl(device, width, height);
+    if (rc != CRT_OK) release_all();           // nothing stays allocated after a failed init
+    return rc;
+}
+
+int crt_shutdown(void)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    release_all();
     return CRT_OK;
 }
 
