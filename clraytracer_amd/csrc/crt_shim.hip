@@ -38,6 +38,8 @@ struct FrameSlot {
     uint32_t* order = nullptr; uint32_t* len = nullptr; uint32_t* cost = nullptr;   // feedback launch lists
     size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 };
     bool listsReady = false;                   // the lists for the next frame were already sorted at the end of the last one
+    // CRT_RENDER_READBACK: pinned host copy of this slot's frame, queued behind the frame on the slot's stream
+    void* hostBuf = nullptr; size_t hostCap = 0, hostBytes = 0; uint32_t* packBuf = nullptr; size_t packCap = 0; hipEvent_t copied = nullptr;
 };
 
 struct State {
@@ -49,6 +51,7 @@ struct State {
     FrameSlot slot[CRT_MAX_FRAMES_IN_FLIGHT]; int nSlots = 3;
     hipStream_t stream = nullptr;              // == slot[0].stream: uploads, queries, diagnostics
     int cur = 0;                               // slot of the most recently submitted frame
+    int readbackSlot = -1;                     // slot of the most recent CRT_RENDER_READBACK frame
     unsigned asyncSeq = 0; bool othersBusy = false;   // frames possibly running on slots > 0
     int width = 0, height = 0;
     int bandRows = 16, rank = 0, nRanks = 1;
@@ -156,7 +159,7 @@ int alloc_frame_buffers(int w, int h)
         HIPCHK(hipMemsetAsync(fs.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
     }
     HIPCHK(hipStreamSynchronize(g.stream));
-    g.width = w; g.height = h;
+    g.width = w; g.height = h; g.readbackSlot = -1;
     return CRT_OK;
 }
 
@@ -450,7 +453,11 @@ static void release_all()
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.instances, g.instBounds, g.tlas, g.alwaysList, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
-    for (FrameSlot& fs : g.slot) { void* q[] = { fs.out, fs.order, fs.len, fs.cost }; for (void* p : q) if (p) (void)hipFree(p); }
+    for (FrameSlot& fs : g.slot) {
+        void* q[] = { fs.out, fs.order, fs.len, fs.cost, fs.packBuf }; for (void* p : q) if (p) (void)hipFree(p);
+        if (fs.hostBuf) (void)hipHostFree(fs.hostBuf);
+        if (fs.copied) (void)hipEventDestroy(fs.copied);
+    }
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.statStart) (void)hipEventDestroy(g.statStart);
     for (FrameSlot& fs : g.slot) {
@@ -942,6 +949,34 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
     const bool sorted = F.order != nullptr && !g.ldsTiles;
     if (sorted) { rc = sort_for_next_frame(F, fs, pipelined); if (rc) return rc; }
+    if (flags & CRT_RENDER_READBACK) {
+        // the frame travels to pinned host memory behind its own kernels; the other slots' frames keep the GPU busy meanwhile
+        const size_t pixels = (size_t)g.width * (size_t)g.height;
+        const bool bytes8 = (flags & CRT_RENDER_UNORM8) != 0;
+        const size_t bytes = pixels * (bytes8 ? 4 : 16);
+        if (bytes > fs.hostCap) {
+            if (fs.hostBuf) (void)hipHostFree(fs.hostBuf);
+            fs.hostBuf = nullptr; fs.hostCap = 0;
+            HIPCHK(hipHostMalloc(&fs.hostBuf, bytes, hipHostMallocDefault));
+            fs.hostCap = bytes;
+        }
+        if (!fs.copied) HIPCHK(hipEventCreateWithFlags(&fs.copied, hipEventDisableTiming));
+        const void* src = fs.out;
+        if (bytes8) {
+            if (pixels * 4 > fs.packCap) {
+                if (fs.packBuf) (void)hipFree(fs.packBuf);
+                fs.packBuf = nullptr; fs.packCap = 0;
+                HIPCHK(hipMalloc(&fs.packBuf, pixels * 4));
+                fs.packCap = pixels * 4;
+            }
+            crt_pack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, fs.stream>>>(fs.out, fs.packBuf, pixels);
+            HIPCHK(hipGetLastError());
+            src = fs.packBuf;
+        }
+        HIPCHK(hipMemcpyAsync(fs.hostBuf, src, bytes, hipMemcpyDeviceToHost, fs.stream));
+        HIPCHK(hipEventRecord(fs.copied, fs.stream));
+        fs.hostBytes = bytes; g.readbackSlot = slot;
+    }
     // the reference's clFinish (Renderer.cpp:367): wait for the frame's end event -- the sort for the next frame that is
     // queued behind it needs no waiting for
     if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipEventSynchronize(es.evPost ? es.ev[3] : es.ev[2]));
@@ -1026,6 +1061,17 @@ int crt_read_output_rgba8(uint8_t* dst, size_t bytes)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(dst, g.queryBuf, pixels * 4, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
+}
+
+int crt_map_host_frame(const void** ptr, size_t* bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!ptr || g.readbackSlot < 0) return CRT_E_BAD_ARGUMENT;
+    FrameSlot& fs = g.slot[g.readbackSlot];
+    HIPCHK(hipEventSynchronize(fs.copied));
+    *ptr = fs.hostBuf;
+    if (bytes) *bytes = fs.hostBytes;
     return CRT_OK;
 }
 

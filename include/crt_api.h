@@ -44,6 +44,8 @@ enum {
     CRT_RENDER_STAMPS      = 16,  /* diagnostic launch: per-wave start/end clock stamps (crt_debug_read_stamps) */
     CRT_RENDER_UNORM8      = 64,  /* hazard H8: upstream renders into an RGBA8-UNORM texture (Renderer.cpp:63,192): quantise the
                                      Trace result like write_imagef/read_imagef before PostProcess and the final frame after it */
+    CRT_RENDER_READBACK    = 128, /* also copy the finished frame to pinned host memory behind its kernels (float4, or RGBA8 bytes
+                                     with CRT_RENDER_UNORM8); fetch it with crt_map_host_frame. Overlaps with the other frames in flight */
     CRT_RENDER_SHADOWS     = 32   /* extension (kernel_main.cl:256-258 is a TODO upstream): one any-hit shadow ray from the first
                                      hit towards the sun sets the `shadow` factor of kernel_main.cl:264; see DESIGN.md */
 };
@@ -118,6 +120,9 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
 int crt_read_output(float* dstRGBA, size_t floats);           /* full frame, width*height*4 floats */
 int crt_read_output_rows(float* dstRGBA, int row0, int rows); /* rows [row0,row0+rows) */
 int crt_read_output_rgba8(uint8_t* dstRGBA, size_t bytes);    /* the frame as RGBA8 (convert_uchar_sat_rte(x*255)), width*height*4 bytes */
+/* Host copy of the most recent CRT_RENDER_READBACK frame: waits for that copy only; the pointer (pinned memory owned by
+ * the library) stays valid until as many further READBACK frames as there are frame slots have been submitted. */
+int crt_map_host_frame(const void** ptr, size_t* bytes);
 int crt_read_rays(float* dst, size_t floats);                 /* width*height*3, after WRITE_RAYS */
 void* crt_output_device_ptr(void);
 int crt_owned_rows(void);                                     /* rows this rank renders per frame */

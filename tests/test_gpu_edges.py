@@ -252,3 +252,29 @@ def test_empty_inputs(nthreads):
                 assert st["hits"] == 0 and st["misses"] == 256 and st["traversals"] == 0
         assert hip.crt_query_hits(None, None, 0, 0, None) == 0
         assert hip.crt_upload_triangles(None, 0, 0) == 0 and hip.crt_upload_instances(None, 0, 0) == 0
+
+
+def test_readback_frames_arrive_in_pinned_host_memory(nthreads):
+    """CRT_RENDER_READBACK: the frame (float4, or RGBA8 with UNORM8) is copied to pinned host memory behind its own
+    kernels; crt_map_host_frame returns the copy of the most recent such frame, for synchronous frames and frames in flight."""
+    sc = scenes.get("tiny")
+    READBACK, ASYNC, UNORM8 = 128, 4, 64
+    hip = _lib.hip()
+    with driver.Session(200, 120, device=0) as s:
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        ref, _ = orc.trace(orc.raygen(200, 120, iv, ip), pos, sc.sun_angle)
+        ptr, n = C.c_void_p(), C.c_size_t()
+        assert hip.crt_map_host_frame(C.byref(ptr), C.byref(n)) == -2          # nothing read back yet
+        for flags in (READBACK, READBACK | ASYNC, READBACK | ASYNC, READBACK | ASYNC, READBACK | ASYNC):
+            s.render_raw(flags)
+            assert hip.crt_map_host_frame(C.byref(ptr), C.byref(n)) == 0 and n.value == 200 * 120 * 16
+            got = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(120, 200, 4))
+            assert np.array_equal(bits(got), bits(ref)), flags
+        s.render_raw(READBACK | ASYNC | UNORM8)
+        assert hip.crt_map_host_frame(C.byref(ptr), C.byref(n)) == 0 and n.value == 200 * 120 * 4
+        got8 = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(120, 200, 4))
+        assert np.array_equal(got8, orc.pack_unorm8(ref))
+        s.resize(96, 64)
+        assert hip.crt_map_host_frame(C.byref(ptr), C.byref(n)) == -2          # the old frame's geometry is gone
