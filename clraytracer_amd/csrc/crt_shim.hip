@@ -46,7 +46,7 @@ struct State {
     bool initialized = false;
     int device = -1;
     char deviceName[256] = { 0 };
-    // Frame slots: a synchronous frame always uses slot 0; CRT_RENDER_ASYNC frames alternate between the two slots
+    // Frame slots: a synchronous frame always uses slot 0; CRT_RENDER_ASYNC frames rotate over the first nSlots slots
     // (own stream, output buffer, launch lists and events each), so the tail of one frame overlaps the next.
     FrameSlot slot[CRT_MAX_FRAMES_IN_FLIGHT]; int nSlots = 3;
     hipStream_t stream = nullptr;              // == slot[0].stream: uploads, queries, diagnostics
@@ -901,7 +901,7 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     if (F.gridBlocks == 0) return CRT_OK;
     unsigned grid = (unsigned)F.gridBlocks;
 
-    // Slot choice: plain ASYNC frames of the default kernel alternate between the two slots so consecutive frames
+    // Slot choice: plain ASYNC frames of the default kernel rotate over the frame slots so consecutive frames
     // overlap (each slot has its own stream, output buffer and launch lists). Everything else -- synchronous frames,
     // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
     const bool variant = g.persistent || g.wavefront || g.ldsTiles;
