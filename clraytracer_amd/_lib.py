@@ -80,6 +80,7 @@ HIP_API = {
     "crt_read_output_rows": (C.c_int, [_vp, C.c_int, C.c_int]),
     "crt_read_output_rgba8": (C.c_int, [_vp, _sz]),
     "crt_map_host_frame": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "crt_map_host_frame_back": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "crt_read_rays": (C.c_int, [_vp, _sz]),
     "crt_output_device_ptr": (_vp, []),
     "crt_owned_rows": (C.c_int, []),

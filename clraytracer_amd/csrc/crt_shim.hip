@@ -40,6 +40,13 @@ struct FrameSlot {
     bool listsReady = false;                   // the lists for the next frame were already sorted at the end of the last one
     // CRT_RENDER_READBACK: pinned host copy of this slot's frame, queued behind the frame on the slot's stream
     void* hostBuf = nullptr; size_t hostCap = 0, hostBytes = 0; uint32_t* packBuf = nullptr; size_t packCap = 0; hipEvent_t copied = nullptr;
+    // This slot's copy of the instance tables (reference-layout records, device records, bounding spheres, instance tree,
+    // never-culled list), refreshed on the slot's own stream from the host master when it is stale (ensure_slot_instances):
+    // an instance upload never has to wait for the frames in flight, and those frames never see it.
+    CrtMeshInstance* instances = nullptr; CrtDevInstance* devInstances = nullptr; float4* instBounds = nullptr;
+    CrtTlasNode* tlas = nullptr; uint32_t* alwaysList = nullptr; uint32_t tlasNodes = 0, numAlways = 0;
+    unsigned long long instVersion = 0;        // 0 = never filled (the master starts at 1)
+    char* staging = nullptr; hipEvent_t staged = nullptr;   // pinned staging block and "its copies have been issued and done" event
 };
 
 struct State {
@@ -51,7 +58,7 @@ struct State {
     FrameSlot slot[CRT_MAX_FRAMES_IN_FLIGHT]; int nSlots = 3;
     hipStream_t stream = nullptr;              // == slot[0].stream: uploads, queries, diagnostics
     int cur = 0;                               // slot of the most recently submitted frame
-    int readbackSlot = -1;                     // slot of the most recent CRT_RENDER_READBACK frame
+    int readbackRing[CRT_MAX_FRAMES_IN_FLIGHT] = { -1, -1, -1, -1 }; unsigned readbackCount = 0;   // slots of the latest CRT_RENDER_READBACK frames
     unsigned asyncSeq = 0; bool othersBusy = false;   // frames possibly running on slots > 0
     int width = 0, height = 0;
     int bandRows = 16, rank = 0, nRanks = 1;
@@ -60,9 +67,12 @@ struct State {
     // CDNA4 layouts
     float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
     uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr; uint32_t* stackOverflow = nullptr;
-    CrtMeshInstance* instances = nullptr; CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
-    float4* instBounds = nullptr; CrtDevInstance* devInstances = nullptr; uint32_t* hotSlot = nullptr;
-    CrtTlasNode* tlas = nullptr; uint32_t* alwaysList = nullptr; uint32_t tlasNodes = 0, numAlways = 0;   // instance tree (rebuild_instance_bounds)
+    CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
+    uint32_t* hotSlot = nullptr;
+    // host master of everything derived from the instance table (rebuild_instance_master); slots copy it when stale
+    float4 hBounds[CRT_MAX_INSTANCES]; CrtTlasNode hTlas[2 * CRT_MAX_INSTANCES]; uint32_t hAlways[CRT_MAX_INSTANCES];
+    uint32_t hTlasNodes = 0, hNumAlways = 0; unsigned long long instVersion = 1;
+    CrtBVHNode hRootNodes[CRT_MAX_MESHES]; bool hHaveRoot[CRT_MAX_MESHES];   // root node of every mesh, cached at BVH upload
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
     float* rays = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
@@ -136,14 +146,14 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
     F.rank = g.rank; F.nRanks = g.nRanks;
 }
 
-void fill_scene(CrtDevScene& S, uint32_t numInstances)
+void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs)
 {
     S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs; S.stackOverflow = g.stackOverflow;
-    S.instances = g.instances; S.devInstances = g.devInstances; S.instBounds = g.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
+    S.instances = fs.instances; S.devInstances = fs.devInstances; S.instBounds = fs.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
     S.numTexels = (int)((g.texelBytesHigh + 2) / 3);
     if (S.numTexels < 1) S.numTexels = 1;
     S.numInstances = numInstances;
-    S.tlas = g.tlas; S.tlasNodes = g.tlasNodes; S.alwaysList = g.alwaysList; S.numAlways = g.numAlways;
+    S.tlas = fs.tlas; S.tlasNodes = fs.tlasNodes; S.alwaysList = fs.alwaysList; S.numAlways = fs.numAlways;
 }
 
 int alloc_frame_buffers(int w, int h)
@@ -159,11 +169,12 @@ int alloc_frame_buffers(int w, int h)
         HIPCHK(hipMemsetAsync(fs.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
     }
     HIPCHK(hipStreamSynchronize(g.stream));
-    g.width = w; g.height = h; g.readbackSlot = -1;
+    g.width = w; g.height = h; g.readbackCount = 0;
     return CRT_OK;
 }
 
-int rebuild_instance_bounds();
+int cache_root_nodes();
+void rebuild_instance_master();
 
 int rebuild_bvh_layout()
 {
@@ -189,7 +200,9 @@ int rebuild_bvh_layout()
     HIPCHK(hipStreamSynchronize(g.stream));
     g.sceneValid = (err == 0);
     if (err) return CRT_E_BAD_ARGUMENT;
-    return rebuild_instance_bounds();
+    RCCHK(cache_root_nodes());
+    rebuild_instance_master();          // root references and root boxes feed the per-instance records
+    return CRT_OK;
 }
 
 // World-space bounding spheres for the conservative instance cull (crt_device.h). Runs at upload
@@ -211,16 +224,25 @@ bool invert4(const double m[16], double out[16])
     return true;
 }
 
-int rebuild_instance_bounds()
+// Root node of every mesh, read back once per BVH upload (everything is quiescent then): instance uploads need the root
+// boxes and must not touch the device.
+int cache_root_nodes()
 {
-    static float4 bounds[CRT_MAX_INSTANCES];
-    static CrtBVHNode rootNodes[CRT_MAX_MESHES];
-    static bool haveRoot[CRT_MAX_MESHES];
     for (uint32_t m = 0; m < CRT_MAX_MESHES; ++m) {
-        haveRoot[m] = m < g.numRoots && g.hRoots[m] < g.nodeCount;
-        if (haveRoot[m]) HIPCHK(hipMemcpyAsync(&rootNodes[m], g.rawNodes + g.hRoots[m], sizeof(CrtBVHNode), hipMemcpyDeviceToHost, g.stream));
+        g.hHaveRoot[m] = m < g.numRoots && g.hRoots[m] < g.nodeCount;
+        if (g.hHaveRoot[m]) HIPCHK(hipMemcpyAsync(&g.hRootNodes[m], g.rawNodes + g.hRoots[m], sizeof(CrtBVHNode), hipMemcpyDeviceToHost, g.stream));
     }
     HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
+}
+
+// Host master of the instance-derived tables: bounding spheres, the instance tree, the never-culled list. Pure host work
+// (a few tens of microseconds for 401 instances); bumps the version the frame slots compare against.
+void rebuild_instance_master()
+{
+    float4* bounds = g.hBounds;
+    const CrtBVHNode* rootNodes = g.hRootNodes;
+    const bool* haveRoot = g.hHaveRoot;
     for (uint32_t i = 0; i < CRT_MAX_INSTANCES; ++i) {
         bounds[i] = make_float4(0.f, 0.f, 0.f, -1.0f);
         if (i >= g.instHigh) continue;
@@ -250,13 +272,12 @@ int rebuild_instance_bounds()
         if (!(isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w)) || !(b.w < 1e18f)) continue;
         bounds[i] = b;
     }
-    HIPCHK(hipMemcpyAsync(g.instBounds, bounds, sizeof bounds, hipMemcpyHostToDevice, g.stream));
     // Instance tree for scenes with many instances (closest_hit<..., TLAS>): median-split binary tree over the cullable
     // instances' spheres, node sphere = centre and half diagonal of the box around its children's spheres. Instances
     // that are never culled go to a separate ascending list.
     {
-        static CrtTlasNode nodes[2 * CRT_MAX_INSTANCES];
-        static uint32_t always[CRT_MAX_INSTANCES];
+        CrtTlasNode* nodes = g.hTlas;
+        uint32_t* always = g.hAlways;
         uint32_t nAlways = 0, nLeaves = 0, nNodes = 0;
         uint32_t leaves[CRT_MAX_INSTANCES];
         // only instances that were uploaded; a frame that asks for more (never-uploaded, all-zero records) uses the linear loop
@@ -294,13 +315,35 @@ int rebuild_instance_bounds()
                 stack[sp++] = Range{ r.lo, mid, n.left };
             }
         }
-        if (nNodes) HIPCHK(hipMemcpyAsync(g.tlas, nodes, nNodes * sizeof(CrtTlasNode), hipMemcpyHostToDevice, g.stream));
-        if (nAlways) HIPCHK(hipMemcpyAsync(g.alwaysList, always, nAlways * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-        g.tlasNodes = nNodes; g.numAlways = nAlways;
+        g.hTlasNodes = nNodes; g.hNumAlways = nAlways;
     }
-    crt_relayout_instances<<<(CRT_MAX_INSTANCES + 255) / 256, 256, 0, g.stream>>>(g.instances, g.rootRefs, CRT_MAX_INSTANCES, g.devInstances);
+    g.instVersion++;
+}
+
+// Offsets of the tables inside a slot's pinned staging block
+constexpr size_t kStageInst = 0;
+constexpr size_t kStageBounds = (kStageInst + CRT_MAX_INSTANCES * sizeof(CrtMeshInstance) + 255) & ~(size_t)255;
+constexpr size_t kStageTlas = (kStageBounds + CRT_MAX_INSTANCES * sizeof(float4) + 255) & ~(size_t)255;
+constexpr size_t kStageAlways = (kStageTlas + 2 * CRT_MAX_INSTANCES * sizeof(CrtTlasNode) + 255) & ~(size_t)255;
+constexpr size_t kStageBytes = kStageAlways + CRT_MAX_INSTANCES * sizeof(uint32_t);
+
+// Brings a slot's instance tables up to the host master, on the slot's own stream, before a frame (or query) uses them.
+int ensure_slot_instances(FrameSlot& fs)
+{
+    if (fs.instVersion == g.instVersion) return CRT_OK;
+    HIPCHK(hipEventSynchronize(fs.staged));                        // the previous refresh no longer reads the staging block
+    memcpy(fs.staging + kStageInst, g.hInstances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance));
+    memcpy(fs.staging + kStageBounds, g.hBounds, CRT_MAX_INSTANCES * sizeof(float4));
+    if (g.hTlasNodes) memcpy(fs.staging + kStageTlas, g.hTlas, g.hTlasNodes * sizeof(CrtTlasNode));
+    if (g.hNumAlways) memcpy(fs.staging + kStageAlways, g.hAlways, g.hNumAlways * sizeof(uint32_t));
+    HIPCHK(hipMemcpyAsync(fs.instances, fs.staging + kStageInst, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance), hipMemcpyHostToDevice, fs.stream));
+    HIPCHK(hipMemcpyAsync(fs.instBounds, fs.staging + kStageBounds, CRT_MAX_INSTANCES * sizeof(float4), hipMemcpyHostToDevice, fs.stream));
+    if (g.hTlasNodes) HIPCHK(hipMemcpyAsync(fs.tlas, fs.staging + kStageTlas, g.hTlasNodes * sizeof(CrtTlasNode), hipMemcpyHostToDevice, fs.stream));
+    if (g.hNumAlways) HIPCHK(hipMemcpyAsync(fs.alwaysList, fs.staging + kStageAlways, g.hNumAlways * sizeof(uint32_t), hipMemcpyHostToDevice, fs.stream));
+    HIPCHK(hipEventRecord(fs.staged, fs.stream));
+    crt_relayout_instances<<<(CRT_MAX_INSTANCES + 255) / 256, 256, 0, fs.stream>>>(fs.instances, g.rootRefs, CRT_MAX_INSTANCES, fs.devInstances);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(g.stream));
+    fs.tlasNodes = g.hTlasNodes; fs.numAlways = g.hNumAlways; fs.instVersion = g.instVersion;
     return CRT_OK;
 }
 
@@ -384,6 +427,15 @@ static int init_impl(int device, int width, int height)
     for (FrameSlot& fs : g.slot) {
         HIPCHK(hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
         for (EventSet& es : fs.es) for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&es.ev[i]));
+        HIPCHK(hipMalloc(&fs.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
+        HIPCHK(hipMalloc(&fs.devInstances, CRT_MAX_INSTANCES * sizeof(CrtDevInstance)));
+        HIPCHK(hipMalloc(&fs.instBounds, CRT_MAX_INSTANCES * sizeof(float4)));
+        HIPCHK(hipMalloc(&fs.tlas, 2 * CRT_MAX_INSTANCES * sizeof(CrtTlasNode)));
+        HIPCHK(hipMalloc(&fs.alwaysList, CRT_MAX_INSTANCES * sizeof(uint32_t)));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&fs.staging), kStageBytes, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&fs.staged, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(fs.staged, fs.stream));
+        fs.instVersion = 0;
     }
     HIPCHK(hipEventCreate(&g.statStart));
     g.stream = g.slot[0].stream; g.cur = 0; g.asyncSeq = 0; g.othersBusy = false;
@@ -405,11 +457,6 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.rootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.stackOverflow, CRT_OVF_WORDS * sizeof(uint32_t)));   // 224 MiB, never touched unless a stack passes 25 entries
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&g.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
-    HIPCHK(hipMalloc(&g.instBounds, CRT_MAX_INSTANCES * sizeof(float4)));
-    HIPCHK(hipMalloc(&g.tlas, 2 * CRT_MAX_INSTANCES * sizeof(CrtTlasNode)));
-    HIPCHK(hipMalloc(&g.alwaysList, CRT_MAX_INSTANCES * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&g.devInstances, CRT_MAX_INSTANCES * sizeof(CrtDevInstance)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMalloc(&g.counters, CRT_NUM_COUNTERS * sizeof(unsigned long long)));
@@ -430,13 +477,13 @@ static int init_impl(int device, int width, int height)
     { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.rootRefs, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
-    HIPCHK(hipMemset(g.instances, 0, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
     HIPCHK(hipMemset(g.materials, 0, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMemset(g.textures, 0, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMemset(g.texels, 0, 64));
     g.nodeCount = 0; g.numRoots = 0; g.texelBytesHigh = 0; g.trisHigh = 0; g.sceneValid = true; g.instHigh = 0;
     memset(g.hInstances, 0, sizeof g.hInstances); memset(g.hRoots, 0, sizeof g.hRoots);
-    { int rcb = rebuild_instance_bounds(); if (rcb) return rcb; }
+    memset(g.hHaveRoot, 0, sizeof g.hHaveRoot); g.instVersion = 1;
+    rebuild_instance_master();
     g.bandRows = 16; g.rank = 0; g.nRanks = 1;
     int rc = alloc_frame_buffers(width, height);
     if (rc) return rc;
@@ -451,10 +498,13 @@ static void release_all()
 {
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.instances, g.instBounds, g.tlas, g.alwaysList, g.devInstances, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
+                     g.texels, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
     for (FrameSlot& fs : g.slot) {
-        void* q[] = { fs.out, fs.order, fs.len, fs.cost, fs.packBuf }; for (void* p : q) if (p) (void)hipFree(p);
+        void* q[] = { fs.out, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
+        for (void* p : q) if (p) (void)hipFree(p);
+        if (fs.staging) (void)hipHostFree(fs.staging);
+        if (fs.staged) (void)hipEventDestroy(fs.staged);
         if (fs.hostBuf) (void)hipHostFree(fs.hostBuf);
         if (fs.copied) (void)hipEventDestroy(fs.copied);
     }
@@ -608,12 +658,12 @@ int crt_upload_instances(const void* instances, size_t first, size_t count)
     if (first + count > CRT_MAX_INSTANCES) return CRT_E_OUT_OF_RANGE;
     const CrtMeshInstance* in = static_cast<const CrtMeshInstance*>(instances);
     for (size_t i = 0; i < count; ++i) if (in[i].meshIndex >= CRT_MAX_MESHES) return CRT_E_BAD_ARGUMENT;
-    RCCHK(quiesce());
-    HIPCHK(hipMemcpyAsync(g.instances + first, instances, count * sizeof(CrtMeshInstance), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
+    // host only: frames already submitted keep the tables they were submitted with, every later frame (on whichever
+    // slot) refreshes its slot's copy on its own stream first -- an animated scene stays pipelined
     memcpy(g.hInstances + first, instances, count * sizeof(CrtMeshInstance));
     if (first + count > g.instHigh) g.instHigh = (uint32_t)(first + count);
-    return rebuild_instance_bounds();
+    rebuild_instance_master();
+    return CRT_OK;
 }
 
 // BuildBVH on the device (crt_bvh_build.h): same triangle order, node numbering and bounds as the host builder.
@@ -876,7 +926,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
                                            : ((flags & CRT_RENDER_ASYNC) != 0
                                               && 2 * tiles * (size_t)g.nSlots >= (size_t)13 * (size_t)g.numCUs * 4 * CRT_WAVES_PER_SIMD_WIDE);
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
-        const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && g.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && g.tlasNodes > 0);
+        const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
 #define CRT_LAUNCH_TRACE(C_, S_, W_) do { if (tlas) crt_trace_kernel<C_, false, S_, W_, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
                                           else crt_trace_kernel<C_, false, S_, W_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
         if (count) { if (shadow) { if (wide) CRT_LAUNCH_TRACE(true, true, true); else CRT_LAUNCH_TRACE(true, true, false); }
@@ -897,7 +947,6 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
     int rc = CRT_OK;
     CrtFrame F; fill_frame(F, args, invView, invProj);
-    CrtDevScene S; fill_scene(S, args->numMeshes);
     if (F.gridBlocks == 0) return CRT_OK;
     unsigned grid = (unsigned)F.gridBlocks;
 
@@ -917,6 +966,9 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     if (rc) return rc;
     if (flags & CRT_RENDER_COUNTERS) { rc = collect_timing(); if (rc) return rc; }
     if (slot != 0) g.othersBusy = true;
+    rc = ensure_slot_instances(fs);          // this slot's instance tables, refreshed on its stream if an upload happened since
+    if (rc) return rc;
+    CrtDevScene S; fill_scene(S, args->numMeshes, fs);
     if (g.feedback && !g.persistent && !g.wavefront) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
 
     // events: [0] frame start, [1] Trace start, [2] Trace end, [3] end of PostProcess = frame end.
@@ -975,7 +1027,7 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
         }
         HIPCHK(hipMemcpyAsync(fs.hostBuf, src, bytes, hipMemcpyDeviceToHost, fs.stream));
         HIPCHK(hipEventRecord(fs.copied, fs.stream));
-        fs.hostBytes = bytes; g.readbackSlot = slot;
+        fs.hostBytes = bytes; g.readbackRing[g.readbackCount++ % CRT_MAX_FRAMES_IN_FLIGHT] = slot;
     }
     // the reference's clFinish (Renderer.cpp:367): wait for the frame's end event -- the sort for the next frame that is
     // queued behind it needs no waiting for
@@ -1011,8 +1063,10 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     HIPCHK(hipMemcpyAsync(dO, origins, rayBytes, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(dD, dirs, rayBytes, hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), g.stream));
-    CrtDevScene S; fill_scene(S, numInstances);
-    const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && g.tlasNodes > 0 && numInstances <= g.instHigh) : (numInstances > CRT_TLAS_MIN_INSTANCES && numInstances <= g.instHigh && g.tlasNodes > 0);
+    FrameSlot& fs = g.slot[0];
+    RCCHK(ensure_slot_instances(fs));
+    CrtDevScene S; fill_scene(S, numInstances, fs);
+    const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && numInstances <= g.instHigh) : (numInstances > CRT_TLAS_MIN_INSTANCES && numInstances <= g.instHigh && fs.tlasNodes > 0);
     if (tlas) crt_query_kernel<true><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
     else crt_query_kernel<false><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
     HIPCHK(hipGetLastError());
@@ -1064,16 +1118,22 @@ int crt_read_output_rgba8(uint8_t* dst, size_t bytes)
     return CRT_OK;
 }
 
-int crt_map_host_frame(const void** ptr, size_t* bytes)
+int crt_map_host_frame_back(int framesBack, const void** ptr, size_t* bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    if (!ptr || g.readbackSlot < 0) return CRT_E_BAD_ARGUMENT;
-    FrameSlot& fs = g.slot[g.readbackSlot];
+    // a pipelined frame's copy lives in its slot until the slot is reused: the last nSlots READBACK frames are reachable
+    if (!ptr || framesBack < 0 || (unsigned)framesBack >= g.readbackCount || framesBack >= g.nSlots) return CRT_E_BAD_ARGUMENT;
+    const int slot = g.readbackRing[(g.readbackCount - 1u - (unsigned)framesBack) % CRT_MAX_FRAMES_IN_FLIGHT];
+    for (int k = 0; k < framesBack; ++k)      // a later frame on the same slot (synchronous frames all use slot 0) has replaced it
+        if (g.readbackRing[(g.readbackCount - 1u - (unsigned)k) % CRT_MAX_FRAMES_IN_FLIGHT] == slot) return CRT_E_BAD_ARGUMENT;
+    FrameSlot& fs = g.slot[slot];
     HIPCHK(hipEventSynchronize(fs.copied));
     *ptr = fs.hostBuf;
     if (bytes) *bytes = fs.hostBytes;
     return CRT_OK;
 }
+
+int crt_map_host_frame(const void** ptr, size_t* bytes) { return crt_map_host_frame_back(0, ptr, bytes); }
 
 int crt_read_rays(float* dst, size_t floats)
 {

@@ -86,7 +86,8 @@ int crt_upload_materials(const void* materials, size_t first, size_t count);
 int crt_upload_texture_table(const void* textures, size_t count);
 /* ResourceManager.cpp:177,203 -- packed RGB8 bytes at a byte offset into the texel pool. */
 int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes);
-/* Renderer.cpp:245,314 */
+/* Renderer.cpp:245,314. Host-side only: the instance table is versioned, frames already submitted keep the version they were
+ * submitted with and every later frame refreshes its slot's device copy on its own stream -- no waiting for frames in flight. */
 int crt_upload_instances(const void* instances, size_t first, size_t count);
 
 /* BuildBVH (BVH.cpp:218-255; called from ResourceManager.cpp:282) on the device, for triangles already uploaded with
@@ -105,8 +106,9 @@ int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count);
  * Frames in flight (no reference counterpart): consecutive CRT_RENDER_ASYNC frames rotate over three frame
  * slots (CRT_FRAMES_IN_FLIGHT=1..4 in the environment, default 3), each with its own HIP stream, output buffer and
  * launch lists, so frames run concurrently and the long-ray tail of one is hidden behind the others; the call
- * blocks only to keep at most two frames queued per slot. Uploads, resize, queries and reads wait for every frame
- * in flight first, so scene edits between frames stay ordered. crt_read_output* and crt_output_device_ptr refer
+ * blocks only to keep at most two frames queued per slot. Mesh / texture / material uploads, resize, queries and reads
+ * wait for every frame in flight first; instance uploads do not need to (see crt_upload_instances). Either way scene
+ * edits between frames stay ordered. crt_read_output* and crt_output_device_ptr refer
  * to the most recently submitted frame. */
 int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags);
 int crt_sync(void);                                           /* wait for every frame in flight */
@@ -123,6 +125,9 @@ int crt_read_output_rgba8(uint8_t* dstRGBA, size_t bytes);    /* the frame as RG
 /* Host copy of the most recent CRT_RENDER_READBACK frame: waits for that copy only; the pointer (pinned memory owned by
  * the library) stays valid until as many further READBACK frames as there are frame slots have been submitted. */
 int crt_map_host_frame(const void** ptr, size_t* bytes);
+/* The same for the READBACK frame submitted `framesBack` READBACK frames earlier (0 = the latest), while its slot has not
+ * been reused: lets a consumer work on frame k-1 while frame k renders. */
+int crt_map_host_frame_back(int framesBack, const void** ptr, size_t* bytes);
 int crt_read_rays(float* dst, size_t floats);                 /* width*height*3, after WRITE_RAYS */
 void* crt_output_device_ptr(void);
 int crt_owned_rows(void);                                     /* rows this rank renders per frame */

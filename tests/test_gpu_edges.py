@@ -278,3 +278,40 @@ def test_readback_frames_arrive_in_pinned_host_memory(nthreads):
         assert np.array_equal(got8, orc.pack_unorm8(ref))
         s.resize(96, 64)
         assert hip.crt_map_host_frame(C.byref(ptr), C.byref(n)) == -2          # the old frame's geometry is gone
+
+
+def test_animated_instances_stay_pipelined_and_ordered(nthreads):
+    """Instance uploads are host-side and versioned: three frames with three different instance tables are submitted
+    back to back (no waiting in between), each must show exactly the table it was submitted with."""
+    sc = scenes.get("tiny")
+    READBACK, ASYNC = 128, 4
+    hip = _lib.hip()
+    W, H = 200, 120
+    with driver.Session(W, H, device=0) as s:
+        s.load_scene(sc)
+        base = s.arenas()
+        iv, ip, pos = s.camera()
+        args, _, _ = s.trace_args()
+        fp = C.POINTER(C.c_float)
+        for _ in range(4):                                   # warm the slots
+            assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), ASYNC) == 0
+        tables = []
+        for k in range(3):
+            inst = base["instances"].copy()
+            inst["inv"][1][3, :3] += np.float32(0.4 * (k + 1))          # inverse transform: translation row
+            inst["inv"][0][3, 1] -= np.float32(0.3 * k)
+            tables.append(inst)
+            assert hip.crt_upload_instances(inst.ctypes.data, 0, len(inst)) == 0
+            assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), ASYNC | READBACK) == 0
+        ptr, n = C.c_void_p(), C.c_size_t()
+        frames = []
+        for back in (2, 1, 0):
+            assert hip.crt_map_host_frame_back(back, C.byref(ptr), C.byref(n)) == 0 and n.value == W * H * 16
+            frames.append(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(H, W, 4)).copy())
+        assert hip.crt_map_host_frame_back(3, C.byref(ptr), C.byref(n)) == -2
+        for k in range(3):
+            a = dict(base); a["instances"] = tables[k]
+            orc = oracle_lib.Oracle(a, nthreads=nthreads)
+            ref, _ = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle)
+            assert np.array_equal(bits(frames[k]), bits(ref)), k
+        assert not np.array_equal(bits(frames[0]), bits(frames[1])) and not np.array_equal(bits(frames[1]), bits(frames[2]))
