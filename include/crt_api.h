@@ -42,12 +42,12 @@ enum {
     CRT_RENDER_ASYNC       = 4,   /* do not wait for completion (the reference always clFinish()es); see crt_render */
     CRT_RENDER_COUNTERS    = 8,   /* instrumented launch that fills the work counters (slower) */
     CRT_RENDER_STAMPS      = 16,  /* diagnostic launch: per-wave start/end clock stamps (crt_debug_read_stamps) */
+    CRT_RENDER_SHADOWS     = 32,  /* extension (kernel_main.cl:256-258 is a TODO upstream): one any-hit shadow ray from the first
+                                     hit towards the sun sets the `shadow` factor of kernel_main.cl:264; see DESIGN.md */
     CRT_RENDER_UNORM8      = 64,  /* hazard H8: upstream renders into an RGBA8-UNORM texture (Renderer.cpp:63,192): quantise the
                                      Trace result like write_imagef/read_imagef before PostProcess and the final frame after it */
-    CRT_RENDER_READBACK    = 128, /* also copy the finished frame to pinned host memory behind its kernels (float4, or RGBA8 bytes
+    CRT_RENDER_READBACK    = 128  /* also copy the finished frame to pinned host memory behind its kernels (float4, or RGBA8 bytes
                                      with CRT_RENDER_UNORM8); fetch it with crt_map_host_frame. Overlaps with the other frames in flight */
-    CRT_RENDER_SHADOWS     = 32   /* extension (kernel_main.cl:256-258 is a TODO upstream): one any-hit shadow ray from the first
-                                     hit towards the sun sets the `shadow` factor of kernel_main.cl:264; see DESIGN.md */
 };
 
 /* Device work counters of the last CRT_RENDER_COUNTERS / crt_query_hits launch. Same meaning as
