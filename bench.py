@@ -86,8 +86,8 @@ def pmc_traffic(kernel, workload_scene, width, height):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="multi-1M")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
