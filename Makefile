@@ -5,12 +5,14 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
 ARCH ?= gfx950
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+# -fno-slp-vectorize: the SLP vectoriser turns the slab tests into v_pk_* with splat operands that cost the trace kernel 20+ VGPRs
+# (96 -> 73) and spilled the 6-waves/SIMD flavour to scratch (290 MB per frame); without it the kernel fits 7 waves/SIMD.
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function
 CXXFLAGS = -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -pthread
 
 HIP_SO = clraytracer_amd/csrc/libcrt_hip.so
 HOST_SO = clraytracer_amd/host/libcrt_host.so
-HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp MeshCache.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp)
+HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp MeshCache.cpp JpegDecode.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp)
 HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
 
 EXAMPLE = examples/crt_headless

@@ -37,63 +37,49 @@
 #define CRT_HOT_PAIRS 1024   // pair indices below this are the trees' top levels (64 KiB: the LDS-staged hot tiles)
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
 #ifndef CRT_WAVES_PER_SIMD
-#define CRT_WAVES_PER_SIMD 5   // 20 waves per CU is what 8 KiB LDS stacks allow (160 KiB / 8 KiB); caps VGPRs at 96
-#endif
-#ifndef CRT_WAVES_PER_SIMD_WIDE
-#define CRT_WAVES_PER_SIMD_WIDE 6   // the flavour for frames in flight: 6400-B LDS stacks, 80 VGPRs (CrtStackT below); 7 is slower (spills)
+#define CRT_WAVES_PER_SIMD 7   // 28 waves per CU: 72 VGPRs (the trace kernel needs 72 without SLP vectorisation) and 5 KiB of LDS each
 #endif
 // Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126), slot indices wrapping modulo 32 where
-// upstream's array would overflow. Two flavours (template parameter LDS_SLOTS of CrtStackT):
-//  * 32: every slot in LDS -- slot s of lane l at lds[s * 64 + l], so a wave's ds_read/ds_write_b32 is conflict-free;
-//    8 KiB per wave, 20 waves per CU (5 per SIMD, 96 VGPRs). Used for synchronous frames, where the latency of the
-//    slowest wave decides the frame.
-//  * 25: slots 0..24 in LDS (6400 B per wave: 24 waves per CU = 6 per SIMD, 80 VGPRs) and slots 25..31, which no
-//    scene here has ever reached (observed depth <= 15), in a global overflow area indexed by the hardware slot the
-//    wave occupies (XCC, SE, SH, CU, SIMD, wave slot from HW_ID / XCC_ID): waves resident at the same time never
-//    share an entry, whatever kernel or stream they belong to, and an entry is always written (push) before it is
-//    read (pop) within one traversal, so the area needs no initialisation. Used for frames in flight, where
-//    throughput decides: +6 % there, -1 % on a synchronous frame (a few spills outside the inner-node loop).
+// upstream's array would overflow. Slots 0..CRT_LDS_SLOTS-1 live in LDS -- slot s of lane l at lds[s * 64 + l], so a
+// wave's ds_read/ds_write_b32 is conflict-free; 20 slots = 5 KiB per wave, which is what lets 28 waves share a CU's
+// 160 KiB. Slots 20..31 (no scene here has passed depth 15; hand-built deep trees in tests/test_gpu_deep_stack.py do)
+// live in a global overflow block owned by the WORKGROUP (blockIdx.x): no two waves of a launch share an entry, every
+// frame slot / query has its own area, and an entry is always written (push) before it is read (pop) within one
+// traversal, so the area needs no initialisation and costs nothing until a stack passes 20 entries.
+// (Round 1 indexed the area by the hardware wave slot from HW_ID; that is only unique while no wave is context-saved
+// and restored elsewhere. Round 1 also had two flavours, 32 LDS slots at 5 waves/SIMD and 25 at 6: the SLP vectoriser's
+// packed-math splats cost 20+ VGPRs and spilled; with -fno-slp-vectorize one 7-waves/SIMD flavour wins everywhere.)
 // (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load.)
 typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
-#ifndef CRT_LDS_SLOTS_WIDE
-#define CRT_LDS_SLOTS_WIDE 25                      // LDS slots of the 6-waves/SIMD flavour
+#ifndef CRT_LDS_SLOTS
+#define CRT_LDS_SLOTS 20
 #endif
-#define CRT_OVF_SLOTS (CRT_STACK_DEPTH - CRT_LDS_SLOTS_WIDE)
-#define CRT_OVF_WAVE_BITS 17                       // wave slot 4 | SIMD 2 | CU+SH 5 | SE 3 | XCC 3
-#define CRT_OVF_WORDS (((size_t)1 << CRT_OVF_WAVE_BITS) * CRT_OVF_SLOTS * 64)
-__device__ __forceinline__ uint32_t* crt_overflow_slot(uint32_t* base, int k)
-{
-    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave[3:0] simd[5:4] cu[11:8] sh[12] se[15:13]
-    const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID[3:0]
-    const uint32_t w = (hw & 0xFu) | (((hw >> 4) & 0x3u) << 4) | (((hw >> 8) & 0x1Fu) << 6) | (((hw >> 13) & 0x7u) << 11) | ((xcc & 0x7u) << 14);
-    uint32_t lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));      // keep the address arithmetic inside this (never taken) branch: hoisted out of the
-                                        // traversal loop it cost two VGPRs, spilled and reloaded at every push and pop
-    return base + ((size_t)w * CRT_OVF_SLOTS + (size_t)k) * 64 + lane;
-}
-template <int LDS_SLOTS>
-struct CrtStackT {
-    static_assert(LDS_SLOTS <= CRT_STACK_DEPTH && LDS_SLOTS >= CRT_LDS_SLOTS_WIDE, "the overflow area holds CRT_STACK_DEPTH - CRT_LDS_SLOTS_WIDE slots per wave");
-    static constexpr int kLdsSlots = LDS_SLOTS;
+#define CRT_OVF_SLOTS (CRT_STACK_DEPTH - CRT_LDS_SLOTS)
+#define CRT_OVF_WORDS_PER_BLOCK ((size_t)CRT_OVF_SLOTS * CRT_BLOCK)
+struct CrtStack {
+    static_assert(CRT_LDS_SLOTS >= 1 && CRT_LDS_SLOTS <= CRT_STACK_DEPTH, "LDS slots");
     crt_lds_u32_ptr lds;     // this lane's slot 0
-    uint32_t* ovf;           // base of the overflow area (wave-uniform); unused when every slot is in LDS
+    uint32_t* ovf;           // base of the launch's overflow area (wave-uniform)
+    __device__ __forceinline__ uint32_t* overflow_slot(int k) const
+    {
+        uint32_t lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));      // keep the address arithmetic inside this (rarely taken) branch: hoisted out of the
+                                            // traversal loop it costs two VGPRs for the whole kernel
+        return ovf + ((size_t)blockIdx.x * CRT_OVF_SLOTS + (size_t)k) * CRT_BLOCK + lane;
+    }
     __device__ __forceinline__ void write(int slot, uint32_t v) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
-        if (LDS_SLOTS >= CRT_STACK_DEPTH || s < LDS_SLOTS) lds[s * 64] = v;
-        else *crt_overflow_slot(ovf, s - LDS_SLOTS) = v;
+        if (CRT_LDS_SLOTS >= CRT_STACK_DEPTH || s < CRT_LDS_SLOTS) lds[s * 64] = v;
+        else *overflow_slot(s - CRT_LDS_SLOTS) = v;
     }
     __device__ __forceinline__ uint32_t read(int slot) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
-        if (LDS_SLOTS >= CRT_STACK_DEPTH || s < LDS_SLOTS) return lds[s * 64];
-        return *crt_overflow_slot(ovf, s - LDS_SLOTS);
+        if (CRT_LDS_SLOTS >= CRT_STACK_DEPTH || s < CRT_LDS_SLOTS) return lds[s * 64];
+        return *overflow_slot(s - CRT_LDS_SLOTS);
     }
 };
-#ifndef CRT_LDS_SLOTS_NARROW
-#define CRT_LDS_SLOTS_NARROW CRT_STACK_DEPTH
-#endif
-typedef CrtStackT<CRT_STACK_DEPTH> CrtStack;       // every slot in LDS
 #ifndef CRT_SPLIT_BETA
 #define CRT_SPLIT_BETA 1.2f
 #endif
@@ -119,7 +105,7 @@ struct CrtDevScene {
     const uint4* __restrict__ triCold;
     const uint32_t* __restrict__ bigLeaf;
     const uint32_t* __restrict__ rootRefs;
-    uint32_t* stackOverflow;             // CRT_OVF_WORDS words, see CrtStack
+    uint32_t* stackOverflow;             // this launch's overflow area: CRT_OVF_WORDS_PER_BLOCK words per workgroup, see CrtStack
     const CrtMeshInstance* __restrict__ instances;
     const struct CrtDevInstance* __restrict__ devInstances;
     const float4* __restrict__ instBounds;   // world-space bounding sphere per instance (xyz, r); r < 0: never cull
@@ -150,6 +136,7 @@ struct CrtFrame {
     const uint32_t* listLen;  // entries in each XCD's list (tiles + 3 extra entries per split tile)
     int listCap;              // capacity of one XCD's list = slotsPerXcd + 3 * CRT_MAX_SPLIT
     uint32_t* cost;           // per tile: shader cycles the wave spent on it this frame (feeds the next frame's order)
+    uint32_t smallPacket;     // packets with at most this many working lanes run every step kind per trip (closest_hit)
 };
 
 struct v3 { float x, y, z; };
@@ -289,16 +276,6 @@ __device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
 // so results are bit-identical; only the interleaving between lanes differs.
 // The stack lives in LDS/scratch (CRT_STACK_*); slot indices wrap modulo 32 where upstream's array would overflow.
 // ------------------------------------------------------------------------------------------------
-// How a kernel fetches a child-pair record: straight from HBM/L2 (default), or from the LDS-staged hot tiles when
-// the pair index is below CRT_HOT_PAIRS (crt_ldstile.h).
-struct GlobalPairLoader {
-    __device__ __forceinline__ void operator()(const CrtDevScene& S, uint32_t ref, float4& lmin, float4& lmax, float4& rmin, float4& rmax) const
-    {
-        const float4* p = S.pairs + (size_t)ref * 4;
-        lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
-    }
-};
-
 template <bool COUNT>
 struct Traversal {
     v3 mo, md, inv;               // ray in the current instance's object space (direction not renormalised, hazard H6)
@@ -323,8 +300,7 @@ struct Traversal {
         active = false;
     }
     // `while (currentNodeIndex > 0 && protection++ < 250) node = stack[--currentNodeIndex]` (kernel_main.cl:131-133)
-    template <class Stack>
-    __device__ __forceinline__ void pop_next(const Stack& stack, Closest& c, LaneCounters& lc)
+    __device__ __forceinline__ void pop_next(const CrtStack& stack, Closest& c, LaneCounters& lc)
     {
         if (sp > 0) {
             if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; finish(c); }
@@ -346,11 +322,10 @@ struct Traversal {
         if (COUNT) { lc.traversals++; lc.pops++; }
     }
     // kernel_main.cl:142-157: fetch the child pair, two slab tests, near child first, far child pushed
-    template <class PairLoader, class Stack>
-    __device__ __forceinline__ void inner(const CrtDevScene& S, const PairLoader& loadPair, const Stack& stack, Closest& c, LaneCounters& lc)
+    __device__ __forceinline__ void inner(const CrtDevScene& S, const CrtStack& stack, Closest& c, LaneCounters& lc)
     {
-        float4 lmin, lmax, rmin, rmax;
-        loadPair(S, ref, lmin, lmax, rmin, rmax);
+        const float4* p = S.pairs + (size_t)ref * 4;            // one aligned 64-byte record
+        const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
         if (COUNT) lc.innerVisits++;
         float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
         float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
@@ -372,8 +347,8 @@ struct Traversal {
     }
     // kernel_main.cl:135-140: every triangle of the leaf, then the next pop.
     // ANYHIT (shadow rays): the traversal ends at the first triangle that passes.
-    template <bool ANYHIT = false, class Stack = CrtStack>
-    __device__ __forceinline__ void leaf(const CrtDevScene& S, const Stack& stack, Closest& c, LaneCounters& lc)
+    template <bool ANYHIT = false>
+    __device__ __forceinline__ void leaf(const CrtDevScene& S, const CrtStack& stack, Closest& c, LaneCounters& lc)
     {
         const uint32_t first = ref & 0x00FFFFFFu;
         uint32_t n = (ref >> 24) & 0x7Fu;
@@ -443,8 +418,7 @@ __device__ __forceinline__ uint32_t candidate_list_next(const CandidateList& L, 
     }
     return best;
 }
-template <class Stack>
-__device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d, const Stack& stack, CandidateList& L)
+__device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d, const CrtStack& stack, CandidateList& L)
 {
 #pragma unroll
     for (int k = 0; k < CRT_TLAS_LIST / 2; ++k) L.w[k] = 0xFFFFFFFFu;
@@ -472,7 +446,10 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
 // Packets with at most this many lanes still working advance every lane through every step kind each trip
 // (latency of the longest ray matters, issue slots do not); larger packets vote for one step kind per trip.
 #ifndef CRT_SMALL_PACKET
-#define CRT_SMALL_PACKET 16
+#define CRT_SMALL_PACKET 16          // synchronous frames (and queries): the slowest wave decides
+#endif
+#ifndef CRT_SMALL_PACKET_ASYNC
+#define CRT_SMALL_PACKET_ASYNC 64    // frames in flight: every packet runs every step kind per trip (voting lost 3 % at 7 waves/SIMD)
 #endif
 
 // Closest hit of one ray per lane over all instances (kernel_main.cl:198-217), driven in flat trips:
@@ -485,9 +462,8 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
 // ANYHIT (shadow rays, CRT_RENDER_SHADOWS): a lane stops at the first triangle that passes -- inside the leaf, and
 // for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
 // first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
-template <bool COUNT, bool ITERS = false, class PairLoader = GlobalPairLoader, bool ANYHIT = false, class Stack = CrtStack, bool TLAS = false>
-__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, const Stack& stack, LaneCounters& lc,
-                                               const PairLoader& loadPair = PairLoader())
+template <bool COUNT, bool ITERS = false, bool ANYHIT = false, bool TLAS = false>
+__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, const CrtStack& stack, LaneCounters& lc, uint32_t smallPacket)
 {
     Closest c;
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
@@ -510,7 +486,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
                 const bool wLeaf = !done && T.at_leaf();
                 const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
                 if (nE + nI + nL == 0) break;
-                const bool all = (nE + nI + nL) <= (uint32_t)CRT_SMALL_PACKET;
+                const bool all = (nE + nI + nL) <= smallPacket;
                 const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
                 if (all || (!runI && !runL)) {
                     if (wEnter) {
@@ -525,7 +501,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
                         }
                     }
                 }
-                if (all || runI) { if (!done && T.at_inner()) T.inner(S, loadPair, stack, c, lc); }
+                if (all || runI) { if (!done && T.at_inner()) T.inner(S, stack, c, lc); }
                 if (all || runL) { if (!done && T.at_leaf()) T.template leaf<ANYHIT>(S, stack, c, lc); }
             }
             return c;
@@ -546,7 +522,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
             const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
             if (nE + nI + nL == 0) break;
             if (ITERS) { if (first_active_lane()) lc.pops++; }
-            const bool all = (nE + nI + nL) <= (uint32_t)CRT_SMALL_PACKET;
+            const bool all = (nE + nI + nL) <= smallPacket;
             const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
             if (all || (!runI && !runL)) {
                 if (wEnter) {
@@ -570,7 +546,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
             if (all || runI) {
                 if (!done && T.at_inner()) {
                     if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
-                    T.inner(S, loadPair, stack, c, lc);
+                    T.inner(S, stack, c, lc);
                 }
             }
             if (all || runL) {

@@ -7,8 +7,9 @@
 //   crt_postprocess_kernel  PostProcess (kernel_main.cl:342-359)
 //   crt_query_kernel        closest-hit records for explicit rays (parity tests)
 //   crt_order_kernel        feedback launch lists: per-XCD counting sort of the tiles by last frame's cost
-// Device-side traversal/shading code lives in crt_device.h; crt_persistent.h and crt_ldstile.h hold two further
-// (opt-in) kernel structures that share it.
+// Device-side traversal/shading code lives in crt_device.h. (Two further kernel structures of round 1 -- resident waves
+// pulling tiles from per-XCD queues, and 768-thread workgroups with the hot BVH tiles staged in LDS -- were measured
+// at 1.67 and 2.25 Gray/s against 4.55 for this one and retired in round 2; DESIGN.md keeps the numbers.)
 #pragma once
 #include "crt_device.h"
 
@@ -169,15 +170,13 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
 // after the first hit a shadow ray (new ray origin, -lightDir) decides `shadow` in `energy *= specular`. Traced only
 // where it is observable: at bounce 0 (the energy after bounce 1 is never read) and when n.l > 0 (otherwise the
 // product is 0 whatever the shadow factor).
-// WIDE: the 6-waves/SIMD flavour (25 LDS stack slots + overflow area, crt_device.h) used for frames in flight.
 // TLAS: candidates come from the instance tree instead of the linear sphere loop (scenes with many instances).
-template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool WIDE = false, bool TLAS = false>
-__global__ __launch_bounds__(CRT_BLOCK, WIDE ? CRT_WAVES_PER_SIMD_WIDE : CRT_WAVES_PER_SIMD)
+template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD)
 void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    typedef CrtStackT<WIDE ? CRT_LDS_SLOTS_WIDE : CRT_LDS_SLOTS_NARROW> Stack;
-    __shared__ uint32_t s_stack[Stack::kLdsSlots * CRT_BLOCK];
-    const Stack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
+    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
     if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
@@ -193,7 +192,7 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
         ps.energy = 1.0f;
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT, STAMP, GlobalPairLoader, false, Stack, TLAS>(S, ps.o, ps.d, stack, lc);
+            Closest c = closest_hit<COUNT, STAMP, false, TLAS>(S, ps.o, ps.d, stack, lc, F.smallPacket);
             float ndl = 0.0f;
             bool cont = shade_bounce<SHADOW>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
@@ -202,7 +201,7 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
                 float shadow = 1.0f;
                 if (bounce == 0 && ndl > 0.0f) {
                     if (COUNT) { lc.rays++; lc.shadowRays++; }
-                    const Closest sc = closest_hit<COUNT, false, GlobalPairLoader, true, Stack, TLAS>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc);
+                    const Closest sc = closest_hit<COUNT, false, true, TLAS>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc, F.smallPacket);
                     if (sc.anyHit) { shadow = 0.0f; if (COUNT) lc.shadowHits++; }
                 }
                 ps.energy = ps.energy * specular_x(ndl, shadow);
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_ker
                                                                 unsigned long long* __restrict__ counters,
                                                                 CrtBounceRay* __restrict__ queue, uint32_t* __restrict__ queueCount)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
     const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     int px, py;
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_ker
         ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
         ps.d = raygen_dir(F, px, py);
         if (COUNT) { lc.rays++; lc.primary++; }
-        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc, F.smallPacket);
         cont = shade_bounce(S, c, ps, 0, F.lightY, F.lightZ);
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kern
                                                                unsigned long long* __restrict__ counters,
                                                                const CrtBounceRay* __restrict__ queue, const uint32_t* __restrict__ queueCount)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
     const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     const uint32_t n = *queueCount;
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kern
         const float4 partial = out[r.pixel];
         ps.result = mk3(partial.x, partial.y, partial.z);
         if (COUNT) { lc.rays++; lc.secondary++; }
-        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc, F.smallPacket);
         const bool cont = shade_bounce(S, c, ps, 1, F.lightY, F.lightZ);
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[r.pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
@@ -376,7 +375,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
-    __shared__ uint32_t s_stack[CRT_STACK_DEPTH * CRT_BLOCK];
+    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
     const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
         v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
         v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
         lc.rays++;
-        Closest c = closest_hit<true, false, GlobalPairLoader, false, CrtStack, TLAS>(S, o, d, stack, lc);
+        Closest c = closest_hit<true, false, false, TLAS>(S, o, d, stack, lc, (uint32_t)CRT_SMALL_PACKET);
         CrtRayHit h;
         if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
         else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }
@@ -393,5 +392,3 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kerne
     flush_counters(lc, counters);
 }
 
-#include "crt_persistent.h"
-#include "crt_ldstile.h"

@@ -35,6 +35,7 @@ struct FrameSlot {
     EventSet es[2];                            // two sets, so the host may queue a slot's next frame before reading the last one's timing
     unsigned frames = 0;
     float4* out = nullptr;
+    uint32_t* ovf = nullptr; size_t ovfBlocks = 0;   // traversal-stack overflow area of this slot's launches (CrtStack), one block per workgroup
     uint32_t* order = nullptr; uint32_t* len = nullptr; uint32_t* cost = nullptr;   // feedback launch lists
     size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 };
     bool listsReady = false;                   // the lists for the next frame were already sorted at the end of the last one
@@ -66,7 +67,7 @@ struct State {
     CrtTri* rawTris = nullptr; CrtBVHNode* rawNodes = nullptr; uint32_t* roots = nullptr; uint8_t* rawTexels = nullptr;
     // CDNA4 layouts
     float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
-    uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr; uint32_t* stackOverflow = nullptr;
+    uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr;
     CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
     uint32_t* hotSlot = nullptr;
     // host master of everything derived from the instance table (rebuild_instance_master); slots copy it when stale
@@ -77,12 +78,11 @@ struct State {
     float* rays = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
-    CrtQueues* queues = nullptr; int numCUs = 0; int persistent = 0; int wavesPerCU = 16;
-    int forceWide = -1;   // CRT_WIDE=0/1: force the megakernel flavour (tests); default: chosen per frame
+    int numCUs = 0;
+    uint32_t smallPacket = CRT_SMALL_PACKET, smallPacketAsync = CRT_SMALL_PACKET_ASYNC;   // CrtFrame::smallPacket for synchronous / pipelined frames
     int forceTlas = -1;   // CRT_TLAS=0/1: force the linear / tree candidate search (tests); default: by instance count
     int feedback = 1; int maxSplit = CRT_MAX_SPLIT, maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED;
     float splitBeta = CRT_SPLIT_BETA, splitBetaAsync = CRT_SPLIT_BETA_ASYNC;   // split a tile whose wave would run longer than beta x the XCD's time for the frame
-    int ldsTiles = 0; uint32_t* listNext = nullptr;
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
@@ -148,7 +148,7 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
 
 void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs)
 {
-    S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs; S.stackOverflow = g.stackOverflow;
+    S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs; S.stackOverflow = fs.ovf;
     S.instances = fs.instances; S.devInstances = fs.devInstances; S.instBounds = fs.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
     S.numTexels = (int)((g.texelBytesHigh + 2) / 3);
     if (S.numTexels < 1) S.numTexels = 1;
@@ -156,19 +156,41 @@ void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs)
     S.tlas = fs.tlas; S.tlasNodes = fs.tlasNodes; S.alwaysList = fs.alwaysList; S.numAlways = fs.numAlways;
 }
 
+// The traversal-stack overflow area of a slot must hold one block per workgroup of its largest launch.
+int ensure_overflow(FrameSlot& fs, size_t blocks)
+{
+    if (blocks <= fs.ovfBlocks) return CRT_OK;
+    HIPCHK(hipStreamSynchronize(fs.stream));
+    if (fs.ovf) (void)hipFree(fs.ovf);
+    fs.ovf = nullptr; fs.ovfBlocks = 0;
+    HIPCHK(hipMalloc(&fs.ovf, blocks * CRT_OVF_WORDS_PER_BLOCK * sizeof(uint32_t)));   // never initialised: entries are written before they are read
+    fs.ovfBlocks = blocks;
+    return CRT_OK;
+}
+
+// New frame buffers are allocated first and swapped in only when every allocation succeeded: a failed resize leaves
+// the old frame size fully usable (crt_resize returns the error).
 int alloc_frame_buffers(int w, int h)
 {
-    if (g.rays) { (void)hipFree(g.rays); g.rays = nullptr; }
-    for (FrameSlot& fs : g.slot) if (fs.out) { (void)hipFree(fs.out); fs.out = nullptr; }
-    if (g.bounceQueue) { (void)hipFree(g.bounceQueue); g.bounceQueue = nullptr; }
-    g.bounceCap = (size_t)w * (size_t)h;
-    HIPCHK(hipMalloc(&g.bounceQueue, sizeof(CrtBounceRay) * g.bounceCap));
-    HIPCHK(hipMalloc(&g.rays, sizeof(float) * 3 * (size_t)w * (size_t)h));
-    for (FrameSlot& fs : g.slot) {
-        HIPCHK(hipMalloc(&fs.out, sizeof(float4) * (size_t)w * (size_t)h));
-        HIPCHK(hipMemsetAsync(fs.out, 0, sizeof(float4) * (size_t)w * (size_t)h, g.stream));
+    const size_t pixels = (size_t)w * (size_t)h;
+    float* rays = nullptr; CrtBounceRay* queue = nullptr; float4* outs[CRT_MAX_FRAMES_IN_FLIGHT] = { nullptr, nullptr, nullptr, nullptr };
+    hipError_t e = hipMalloc(&queue, sizeof(CrtBounceRay) * pixels);
+    if (e == hipSuccess) e = hipMalloc(&rays, sizeof(float) * 3 * pixels);
+    for (int i = 0; i < CRT_MAX_FRAMES_IN_FLIGHT && e == hipSuccess; ++i) {
+        e = hipMalloc(&outs[i], sizeof(float4) * pixels);
+        if (e == hipSuccess) e = hipMemsetAsync(outs[i], 0, sizeof(float4) * pixels, g.stream);
     }
-    HIPCHK(hipStreamSynchronize(g.stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) {
+        if (queue) (void)hipFree(queue);
+        if (rays) (void)hipFree(rays);
+        for (float4* o : outs) if (o) (void)hipFree(o);
+        return (int)e;
+    }
+    if (g.rays) (void)hipFree(g.rays);
+    if (g.bounceQueue) (void)hipFree(g.bounceQueue);
+    g.rays = rays; g.bounceQueue = queue; g.bounceCap = pixels;
+    for (int i = 0; i < CRT_MAX_FRAMES_IN_FLIGHT; ++i) { if (g.slot[i].out) (void)hipFree(g.slot[i].out); g.slot[i].out = outs[i]; }
     g.width = w; g.height = h; g.readbackCount = 0;
     return CRT_OK;
 }
@@ -185,6 +207,7 @@ int rebuild_bvh_layout()
             uint32_t perMesh = 1;
             while (perMesh * 2 * g.numRoots <= (uint32_t)CRT_HOT_PAIRS) perMesh *= 2;
             if (perMesh * g.numRoots > (uint32_t)CRT_HOT_PAIRS) perMesh = 0;
+            if (getenv("CRT_NO_HOT")) perMesh = 0;      // experiment: no top-of-tree packing
             crt_assign_hot_slots<<<(g.numRoots + 63) / 64, 64, 0, g.stream>>>(g.rawNodes, g.nodeCount, g.roots, g.numRoots, perMesh, g.hotSlot);
             HIPCHK(hipGetLastError());
         }
@@ -455,26 +478,23 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.triCold, g.triCap * 2 * sizeof(uint4)));
     HIPCHK(hipMalloc(&g.bigLeaf, g.triCap * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.rootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&g.stackOverflow, CRT_OVF_WORDS * sizeof(uint32_t)));   // 224 MiB, never touched unless a stack passes 25 entries
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMalloc(&g.counters, CRT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
-    HIPCHK(hipMalloc(&g.queues, sizeof(CrtQueues)));
     HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&g.listNext, 8 * sizeof(uint32_t)));
     g.numCUs = prop.multiProcessorCount;
-    { const char* e = getenv("CRT_KERNEL"); g.persistent = (e && strcmp(e, "persistent") == 0); g.wavefront = (e && strcmp(e, "wavefront") == 0); g.ldsTiles = (e && strcmp(e, "lds") == 0); }  // default: tile kernel (faster)
+    { const char* e = getenv("CRT_KERNEL"); g.wavefront = (e && strcmp(e, "wavefront") == 0); }  // default: megakernel (faster)
+    { const char* e = getenv("CRT_SMALL_PACKET"); g.smallPacket = e ? (uint32_t)atoi(e) : (uint32_t)CRT_SMALL_PACKET; }
+    { const char* e = getenv("CRT_SMALL_PACKET_ASYNC"); g.smallPacketAsync = e ? (uint32_t)atoi(e) : (uint32_t)CRT_SMALL_PACKET_ASYNC; }
     { const char* e = getenv("CRT_SPLIT_BETA"); g.splitBeta = e ? (float)atof(e) : CRT_SPLIT_BETA; }
     { const char* e = getenv("CRT_SPLIT_BETA_ASYNC"); g.splitBetaAsync = e ? (float)atof(e) : CRT_SPLIT_BETA_ASYNC; }
     { const char* e = getenv("CRT_SPLIT");               // tuning knob: cap on quadrant-split tiles per XCD (both modes)
       if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
       else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
     { const char* e = getenv("CRT_TLAS"); g.forceTlas = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
-    { const char* e = getenv("CRT_WIDE"); g.forceWide = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
-    { const char* e = getenv("CRT_WAVES_PER_CU"); g.wavesPerCU = e ? atoi(e) : 16; if (g.wavesPerCU < 1) g.wavesPerCU = 1; }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.rootRefs, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.materials, 0, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
@@ -499,9 +519,9 @@ static void release_all()
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
-                     g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.queues, g.bounceQueue, g.bounceCount, g.listNext, g.stackOverflow };
+                     g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount };
     for (FrameSlot& fs : g.slot) {
-        void* q[] = { fs.out, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
+        void* q[] = { fs.out, fs.ovf, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
         for (void* p : q) if (p) (void)hipFree(p);
         if (fs.staging) (void)hipHostFree(fs.staging);
         if (fs.staged) (void)hipEventDestroy(fs.staged);
@@ -871,38 +891,16 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
     const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
     if (count) HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), fs.stream));
     if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
-        unsigned waves = grid;
-        if (g.persistent) {
-            const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
-            waves = (unsigned)(g.numCUs * g.wavesPerCU);
-            if (waves > tiles) waves = tiles;
-        }
-        const size_t need = (16 + (size_t)waves * 8) * sizeof(unsigned long long);
+        const size_t need = (16 + (size_t)grid * 8) * sizeof(unsigned long long);
         if (need > g.stampBytes) {
             if (g.stamps) (void)hipFree(g.stamps);
             g.stamps = nullptr; g.stampBytes = 0;
             HIPCHK(hipMalloc(&g.stamps, need));
             g.stampBytes = need;
         }
-        g.stampWaves = waves;
+        g.stampWaves = grid;
         HIPCHK(hipMemsetAsync(g.stamps, 0, need, fs.stream));
-        if (g.persistent) {
-            HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), fs.stream));
-            crt_trace_persistent_kernel<false, true><<<waves, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.stamps, g.queues);
-        } else {
-            crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.stamps);
-        }
-    } else if (g.ldsTiles) {                               // resident 1024-thread workgroups, hot tiles in LDS (crt_ldstile.h)
-        HIPCHK(hipMemsetAsync(g.listNext, 0, 8 * sizeof(uint32_t), fs.stream));
-        if (count) crt_trace_lds_kernel<true><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, fs.stream>>>(S, F, fs.out, g.counters, g.listNext);
-        else crt_trace_lds_kernel<false><<<g.numCUs, 64 * CRT_LDS_WAVES, 0, fs.stream>>>(S, F, fs.out, g.counters, g.listNext);
-    } else if (g.persistent) {                             // resident waves pulling tiles from per-XCD queues
-        const unsigned tiles = (unsigned)F.ownedTileRows * (unsigned)F.tilesX;
-        unsigned waves = (unsigned)(g.numCUs * g.wavesPerCU);
-        if (waves > tiles) waves = tiles;
-        HIPCHK(hipMemsetAsync(g.queues, 0, sizeof(CrtQueues), fs.stream));
-        if (count) crt_trace_persistent_kernel<true><<<waves, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.queues);
-        else crt_trace_persistent_kernel<false><<<waves, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.queues);
+        crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.stamps);
     } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
         const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
         const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
@@ -915,24 +913,14 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
         }
     } else {
-        // default megakernel: <COUNT, STAMP, SHADOW, WIDE>. WIDE (6 waves/SIMD) serves CRT_RENDER_ASYNC frames when the
-        // frames in flight together fill the machine about 6.5 times over -- throughput decides there. A synchronous
-        // frame, or little work in flight (8 ranks at 3840x2160 with two slots: 5.3 rounds of waves), is decided by
-        // its slowest waves and runs faster on the 5-waves/SIMD flavour. Measured, predicted Gray/s for 8 ranks:
-        // 2 slots narrow 41.6 / wide 37.8; 3 slots narrow 44.7 / wide 46.6.
-        const size_t tiles = (size_t)F.ownedTileRows * (size_t)F.tilesX;
+        // default megakernel: <COUNT, STAMP, SHADOW, TLAS>
         const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0;
-        const bool wide = g.forceWide >= 0 ? g.forceWide != 0
-                                           : ((flags & CRT_RENDER_ASYNC) != 0
-                                              && 2 * tiles * (size_t)g.nSlots >= (size_t)13 * (size_t)g.numCUs * 4 * CRT_WAVES_PER_SIMD_WIDE);
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
         const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
-#define CRT_LAUNCH_TRACE(C_, S_, W_) do { if (tlas) crt_trace_kernel<C_, false, S_, W_, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
-                                          else crt_trace_kernel<C_, false, S_, W_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
-        if (count) { if (shadow) { if (wide) CRT_LAUNCH_TRACE(true, true, true); else CRT_LAUNCH_TRACE(true, true, false); }
-                     else        { if (wide) CRT_LAUNCH_TRACE(true, false, true); else CRT_LAUNCH_TRACE(true, false, false); } }
-        else       { if (shadow) { if (wide) CRT_LAUNCH_TRACE(false, true, true); else CRT_LAUNCH_TRACE(false, true, false); }
-                     else        { if (wide) CRT_LAUNCH_TRACE(false, false, true); else CRT_LAUNCH_TRACE(false, false, false); } }
+#define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) crt_trace_kernel<C_, false, S_, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
+                                      else crt_trace_kernel<C_, false, S_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
+        if (count) { if (shadow) CRT_LAUNCH_TRACE(true, true); else CRT_LAUNCH_TRACE(true, false); }
+        else       { if (shadow) CRT_LAUNCH_TRACE(false, true); else CRT_LAUNCH_TRACE(false, false); }
 #undef CRT_LAUNCH_TRACE
     }
     HIPCHK(hipGetLastError());
@@ -953,7 +941,7 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     // Slot choice: plain ASYNC frames of the default kernel rotate over the frame slots so consecutive frames
     // overlap (each slot has its own stream, output buffer and launch lists). Everything else -- synchronous frames,
     // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
-    const bool variant = g.persistent || g.wavefront || g.ldsTiles;
+    const bool variant = g.wavefront != 0;
     if ((flags & CRT_RENDER_SHADOWS) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
     const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
                         && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
@@ -968,8 +956,15 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     if (slot != 0) g.othersBusy = true;
     rc = ensure_slot_instances(fs);          // this slot's instance tables, refreshed on its stream if an upload happened since
     if (rc) return rc;
-    CrtDevScene S; fill_scene(S, args->numMeshes, fs);
-    if (g.feedback && !g.persistent && !g.wavefront) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
+    CrtDevScene S;
+    if (g.feedback && !g.wavefront) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
+    F.smallPacket = pipelined ? g.smallPacketAsync : g.smallPacket;
+    {   // overflow blocks: one per workgroup of the largest launch of this frame (wavefront: the bounce launch may be larger)
+        size_t blocks = grid;
+        if (g.wavefront) { const size_t g2 = ((size_t)F.ownedTileRows * CRT_TILE * (size_t)F.width + CRT_BLOCK - 1) / CRT_BLOCK; if (g2 > blocks) blocks = g2; }
+        rc = ensure_overflow(fs, blocks); if (rc) return rc;
+    }
+    fill_scene(S, args->numMeshes, fs);
 
     // events: [0] frame start, [1] Trace start, [2] Trace end, [3] end of PostProcess = frame end.
     // A plain frame records only two (RayGen is fused, PostProcess off): [0] == [1], [2] == [3].
@@ -999,7 +994,7 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     }
     g.cur = slot;
     es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
-    const bool sorted = F.order != nullptr && !g.ldsTiles;
+    const bool sorted = F.order != nullptr;
     if (sorted) { rc = sort_for_next_frame(F, fs, pipelined); if (rc) return rc; }
     if (flags & CRT_RENDER_READBACK) {
         // the frame travels to pinned host memory behind its own kernels; the other slots' frames keep the GPU busy meanwhile
@@ -1065,6 +1060,7 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), g.stream));
     FrameSlot& fs = g.slot[0];
     RCCHK(ensure_slot_instances(fs));
+    RCCHK(ensure_overflow(fs, (size_t)((n + CRT_BLOCK - 1) / CRT_BLOCK)));
     CrtDevScene S; fill_scene(S, numInstances, fs);
     const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && numInstances <= g.instHigh) : (numInstances > CRT_TLAS_MIN_INSTANCES && numInstances <= g.instHigh && fs.tlasNodes > 0);
     if (tlas) crt_query_kernel<true><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);

@@ -10,10 +10,15 @@
 // ResourceManager.cpp:205, and never stores the two default texels on the host).
 #include "ResourceManager.hpp"
 #include "AssetManager.hpp"
+#include "JpegDecode.hpp"
 #include "../../include/crt_api.h"
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
+#include <dirent.h>
+#include <strings.h>
+#include <sys/stat.h>
 
 constexpr size_t MAX_TEXTURE_MEMORY = CRT_MAX_TEXTURE_BYTES;
 constexpr size_t MAX_TRIANGLES = CRT_MAX_TRIANGLES;
@@ -79,6 +84,63 @@ namespace {
         texture.offset = (int)(lastTextureOffset / 3);
         lastTextureOffset += numBytes;
         return (TextureHandle)numTextures++;
+    }
+
+    std::string assetRoot;           // SetAssetRoot: stands in for the reference's working directory (the folder that holds Assets/)
+
+    // The reference runs on Windows: `map_Kd Assets/sponza/01_ST_KP.JPG` opens `01_St_kp.JPG` there. Resolve a path the
+    // same way: every component that does not exist as written is matched ignoring case against its directory.
+    bool exists(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0; }
+    bool resolve_ignoring_case(const std::string& path, std::string& out)
+    {
+        if (exists(path)) { out = path; return true; }
+        std::string cur = (!path.empty() && path[0] == '/') ? "/" : "";
+        size_t i = 0;
+        while (i < path.size()) {
+            while (i < path.size() && path[i] == '/') ++i;
+            size_t j = i;
+            while (j < path.size() && path[j] != '/') ++j;
+            if (j == i) break;
+            const std::string comp = path.substr(i, j - i);
+            std::string next = cur + comp;
+            if (!exists(next)) {
+                DIR* d = ::opendir(cur.empty() ? "." : cur.c_str());
+                if (!d) return false;
+                bool found = false;
+                while (struct dirent* e = ::readdir(d))
+                    if (::strcasecmp(e->d_name, comp.c_str()) == 0) { next = cur + e->d_name; found = true; break; }
+                ::closedir(d);
+                if (!found) return false;
+            }
+            cur = next;
+            if (j < path.size()) cur += '/';
+            i = j;
+        }
+        out = cur;
+        return exists(out);
+    }
+    // as written (the reference resolves against its CWD), then under the asset root, then next to the mesh file
+    bool resolve_asset(const std::string& p, const std::string& meshDir, std::string& out)
+    {
+        if (resolve_ignoring_case(p, out)) return true;
+        if (!assetRoot.empty() && resolve_ignoring_case(assetRoot + "/" + p, out)) return true;
+        if (!meshDir.empty() && resolve_ignoring_case(meshDir + p, out)) return true;
+        const size_t slash = p.find_last_of('/');
+        if (!meshDir.empty() && slash != std::string::npos && resolve_ignoring_case(meshDir + p.substr(slash + 1), out)) return true;
+        return false;
+    }
+
+    bool read_file(const char* path, std::vector<unsigned char>& bytes)
+    {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) return false;
+        std::fseek(f, 0, SEEK_END);
+        const long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        bool ok = n >= 0;
+        if (ok) { bytes.resize((size_t)n); ok = n == 0 || std::fread(bytes.data(), 1, (size_t)n, f) == (size_t)n; }
+        std::fclose(f);
+        return ok;
     }
 
     bool read_ppm(const char* path, int& w, int& h, std::string& pixels)
@@ -160,11 +222,33 @@ void ResourceManager::Initialize(bool deviceUploads)
     initialized = true;
 }
 
+void ResourceManager::SetAssetRoot(const char* dir) { assetRoot = dir ? dir : ""; while (!assetRoot.empty() && assetRoot.back() == '/') assetRoot.pop_back(); }
+
+// ResourceManager.cpp:180-222: stbi_load(path, &w, &h, &channels, 3) -> RGB8 into the texel arena. JPEG files go through
+// JpegDecode.cpp (same bytes as the reference's stb_image); binary PPM (P6) stays accepted for the synthetic scenes.
 TextureHandle ResourceManager::ImportTexture(const char* path)
 {
+    std::string resolved;
+    if (!resolve_asset(path, std::string(), resolved)) {
+        std::fprintf(stderr, "[ResourceManager] texture importing failed! file is not exist: %s\n", path);
+        lastError = CRT_E_BAD_ARGUMENT; return 0;
+    }
+    std::vector<unsigned char> file;
+    if (!read_file(resolved.c_str(), file) || file.size() < 4) {
+        std::fprintf(stderr, "[ResourceManager] texture importing failed! cannot read: %s\n", resolved.c_str());
+        lastError = CRT_E_BAD_ARGUMENT; return 0;
+    }
+    if (file[0] == 0xFF && file[1] == 0xD8) {
+        JpegInfo info; std::vector<unsigned char> rgb; const char* why = nullptr;
+        if (!JpegDecodeRGB8(file.data(), file.size(), &info, rgb, &why)) {
+            std::fprintf(stderr, "[ResourceManager] texture importing failed! keep in mind texture must be .jpeg (%s: %s)\n", resolved.c_str(), why ? why : "?");
+            lastError = CRT_E_BAD_ARGUMENT; return 0;
+        }
+        return store_texture(path, info.width, info.height, rgb.data());
+    }
     int w = 0, h = 0; std::string px;
-    if (!read_ppm(path, w, h, px)) {
-        std::fprintf(stderr, "[ResourceManager] texture importing failed (binary PPM expected): %s\n", path);
+    if (!read_ppm(resolved.c_str(), w, h, px)) {
+        std::fprintf(stderr, "[ResourceManager] texture importing failed! keep in mind texture must be .jpeg (or binary PPM): %s\n", resolved.c_str());
         lastError = CRT_E_BAD_ARGUMENT; return 0;
     }
     return store_texture(path, w, h, reinterpret_cast<const unsigned char*>(px.data()));
@@ -221,10 +305,11 @@ MeshHandle ResourceManager::ImportMesh(const char* path) // ResourceManager.cpp:
         material.roughness = objMaterial.roughness;
         auto import_map = [&](int offset) -> ushort {
             if (!offset) return 0;
-            std::string p(mesh->mtlText + offset);
-            // upstream resolves map paths against the process CWD; also try the OBJ's directory
-            FILE* probe = std::fopen(p.c_str(), "rb");
-            if (probe) std::fclose(probe); else p = dir + p;
+            // upstream resolves map paths against the process CWD (ignoring case: Windows); also try the asset root and
+            // the mesh file's directory
+            std::string p(mesh->mtlText + offset), found;
+            while (!p.empty() && (p.back() == ' ' || p.back() == '\t' || p.back() == '\r')) p.pop_back();
+            if (resolve_asset(p, dir, found)) p = found;
             return ImportTexture(p.c_str());
         };
         material.albedoTextureIndex = import_map(objMaterial.diffusePath);

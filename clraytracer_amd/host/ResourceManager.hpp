@@ -26,9 +26,13 @@ typedef ushort MaterialHandle;
 
 namespace ResourceManager
 {
-    // path: binary PPM (P6, maxval 255). The reference decodes JPEG through stb_image
-    // (ResourceManager.cpp:193); JPEG import is a "next" row of SURVEY.md 8f.
+    // path: a JPEG (decoded to the same RGB8 bytes as the reference's stbi_load(path, .., 3), ResourceManager.cpp:193;
+    // JpegDecode.hpp) or a binary PPM (P6, maxval 255; the synthetic scenes). The path is tried as written, then under
+    // the asset root, ignoring case per component (the reference's assets rely on Windows path semantics).
     TextureHandle ImportTexture(const char* path);
+    // Extension: where relative asset paths (texture paths inside .mtl / .clm files, e.g. "Assets/sponza/KAMEN.JPG")
+    // resolve when they are not found relative to the working directory -- the folder that contains `Assets/`.
+    void SetAssetRoot(const char* dir);
     // Extension: import from memory (tightly packed RGB8, width*height*3 bytes).
     TextureHandle ImportTextureRGB8(const char* name, int width, int height, const unsigned char* rgb);
     MeshHandle ImportMesh(const char* path);

@@ -3,8 +3,10 @@
 #include "../../include/crt_api.h"
 #include "AssetManager.hpp"
 #include "CPURayTrace.hpp"
+#include "JpegDecode.hpp"
 #include "Renderer.hpp"
 #include <cstdio>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -39,6 +41,16 @@ int crth_import_mesh(const char* path) { return ResourceManager::ImportMesh(path
 void crth_push_meshes(void) { ResourceManager::PushMeshesToGPU(); }
 void crth_set_mesh_cache(int enabled) { AssetManager_SetMeshCache(enabled != 0); }
 size_t crth_qlz_decompress(const unsigned char* src, size_t srcLen, unsigned char* dst, size_t dstCap) { return MeshCache_QlzDecompress(src, srcLen, dst, dstCap); }
+size_t crth_jpeg_decode(const unsigned char* data, size_t size, unsigned char* dst, size_t dstCap, int info[4], const char** error)
+{
+    std::vector<unsigned char> rgb;
+    JpegInfo ji;
+    if (!JpegDecodeRGB8(data, size, &ji, rgb, error)) return 0;
+    if (info) { info[0] = ji.width; info[1] = ji.height; info[2] = ji.components; info[3] = ji.progressive ? 1 : 0; }
+    if (dst) { if (dstCap < rgb.size()) return 0; std::memcpy(dst, rgb.data(), rgb.size()); }
+    return rgb.size();
+}
+void crth_set_asset_root(const char* dir) { ResourceManager::SetAssetRoot(dir); }
 size_t crth_qlz_store(const unsigned char* src, size_t size, unsigned char* dst) { return MeshCache_QlzStore(src, size, dst); }
 void crth_set_device_bvh_build(int enabled) { ResourceManager::SetDeviceBVHBuild(enabled != 0); }
 void crth_push_textures(void) { ResourceManager::PushTexturesToGPU(); }

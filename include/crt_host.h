@@ -29,6 +29,11 @@ void crth_set_device_bvh_build(int enabled);                 /* ResourceManager:
 void crth_set_mesh_cache(int enabled);                       /* AssetManager_SetMeshCache: the `.clm` cache (AssetManager.cpp:291-381), on by default */
 size_t crth_qlz_decompress(const unsigned char* src, size_t srcLen, unsigned char* dst, size_t dstCap); /* QuickLZ 1.5.0 level 1 */
 size_t crth_qlz_store(const unsigned char* src, size_t size, unsigned char* dst);                        /* stored block, size + 9 bytes */
+/* JPEG -> RGB8 as the reference's stbi_load(path, &w, &h, &channels, 3) (ResourceManager.cpp:193). Returns the number of
+ * bytes written (width*height*3), or 0 on failure (*error, if given, names the reason). With dst == NULL only the header is
+ * read: info[0..3] = width, height, components in the file (1 or 3), progressive; the return value is the size needed. */
+size_t crth_jpeg_decode(const unsigned char* data, size_t size, unsigned char* dst, size_t dstCap, int info[4], const char** error);
+void crth_set_asset_root(const char* dir);                   /* ResourceManager::SetAssetRoot: where relative texture paths of .mtl/.clm files resolve */
 void crth_push_textures(void);                               /* ResourceManager::PushTexturesToGPU */
 void crth_push_materials(void);                              /* ResourceManager::PushMaterialsToGPU */
 int crth_create_material(int count);                         /* ResourceManager::CreateMaterial -> first handle, -1 on failure */

@@ -1,6 +1,6 @@
 """Hazard H2: upstream's traversal stack is `int nodesToVisit[32]` with no overflow check (kernel_main.cl:126,154).
-The oracle pins the undefined overflow as "slot index wraps modulo 32"; the HIP path keeps most slots in LDS and the
-rest in a per-wave-slot overflow area and must reproduce exactly that -- including a hand-built 48-level caterpillar
+The oracle pins the undefined overflow as "slot index wraps modulo 32"; the HIP path keeps 20 slots in LDS and the
+other 12 in a per-workgroup overflow area (CrtStack, crt_device.h) and must reproduce exactly that -- including a hand-built 48-level caterpillar
 tree whose rays push 47 far children before the first pop, and the 250-pop cap on a tree deeper than the cap."""
 import ctypes as C
 
@@ -56,15 +56,18 @@ def caterpillar(levels, reverse=False):
     return tris, nodes
 
 
-@pytest.fixture(params=["0", "1"], ids=["lds32", "lds25+overflow"])
-def flavour(request, monkeypatch):
-    """CRT_WIDE (read by crt_init) forces the megakernel flavour, which is otherwise chosen per frame by its size."""
-    monkeypatch.setenv("CRT_WIDE", request.param)
+@pytest.fixture(params=["megakernel", "wavefront"])
+def structure(request, monkeypatch):
+    """CRT_KERNEL (read by crt_init): the default megakernel or the one-launch-per-bounce form; both share CrtStack."""
+    if request.param == "wavefront":
+        monkeypatch.setenv("CRT_KERNEL", "wavefront")
+    else:
+        monkeypatch.delenv("CRT_KERNEL", raising=False)
     return request.param
 
 
-@pytest.mark.parametrize("levels,reverse", [(20, False), (31, False), (34, False), (48, False), (48, True), (300, False)])
-def test_hand_built_deep_tree_matches_oracle(levels, reverse, flavour, nthreads):
+@pytest.mark.parametrize("levels,reverse", [(20, False), (22, False), (31, False), (34, False), (48, False), (48, True), (300, False)])
+def test_hand_built_deep_tree_matches_oracle(levels, reverse, structure, nthreads):
     sc = scenes.get("tiny")
     hip = _lib.hip()
     W, H = (640, 368) if levels == 48 else (96, 64)      # 48 levels: thousands of waves deep in the overflow slots at once
@@ -89,7 +92,7 @@ def test_hand_built_deep_tree_matches_oracle(levels, reverse, flavour, nthreads)
         args.time, args.numMeshes, args.sunAngle = 0.0, 1, float(sc.sun_angle)
         fp = C.POINTER(C.c_float)
         ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle)
-        for flags in (8, 0, 4, 4, 8 | 32):
+        for flags in ((8, 0, 4, 4) if structure == "wavefront" else (8, 0, 4, 4, 8 | 32)):   # shadow rays: default kernel only
             assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), flags) == 0
             if flags & 32:
                 ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle, shadows=True)
