@@ -9,10 +9,8 @@
 //
 // HBM layout (built by the kernels of crt_relayout.h from the reference-layout uploads):
 //   pairs   : one 64-byte, 64-byte-aligned record per sibling pair {L.min,L.ref | L.max,- |
-//             R.min,R.ref | R.max,-}; pair index = CRT_HOT_PAIRS + (leftFirst >> 1) (siblings are adjacent
-//             upstream, BVH.cpp:203-204). One inner-node visit = one aligned 64-byte fetch per lane.
-//             The pairs of the top levels of every tree are duplicated at indices [0, CRT_HOT_PAIRS) and
-//             referenced there (crt_assign_hot_slots): 64 KiB of hot tiles a workgroup can stage in LDS.
+//             R.min,R.ref | R.max,-}; pair index = leftFirst >> 1 (siblings are adjacent upstream,
+//             BVH.cpp:203-204). One inner-node visit = one aligned 64-byte fetch per lane.
 //   ref     : 32-bit child descriptor. Inner: pair index. Leaf: bit31 | count<<24 | firstTri
 //             (count 1..127; 0 = look up CrtDevScene::bigLeaf[firstTri]). A popped/descended node
 //             needs no re-fetch to learn whether it is a leaf (upstream re-reads the 32-byte node).
@@ -34,7 +32,6 @@
 #include "../../include/crt_types.h"
 
 #define CRT_LEAF_BIT 0x80000000u
-#define CRT_HOT_PAIRS 1024   // pair indices below this are the trees' top levels (64 KiB: the LDS-staged hot tiles)
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
 #ifndef CRT_WAVES_PER_SIMD
 #define CRT_WAVES_PER_SIMD 7   // 28 waves per CU: 72 VGPRs (the trace kernel needs 72 without SLP vectorisation) and 5 KiB of LDS each

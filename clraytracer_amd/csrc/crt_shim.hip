@@ -69,7 +69,6 @@ struct State {
     float4* pairs = nullptr; float* triHot = nullptr; uint4* triCold = nullptr; uint32_t* bigLeaf = nullptr;
     uint32_t* rootRefs = nullptr; uint32_t* texels = nullptr;
     CrtMaterial* materials = nullptr; CrtTexture* textures = nullptr;
-    uint32_t* hotSlot = nullptr;
     // host master of everything derived from the instance table (rebuild_instance_master); slots copy it when stale
     float4 hBounds[CRT_MAX_INSTANCES]; CrtTlasNode hTlas[2 * CRT_MAX_INSTANCES]; uint32_t hAlways[CRT_MAX_INSTANCES];
     uint32_t hTlasNodes = 0, hNumAlways = 0; unsigned long long instVersion = 1;
@@ -202,22 +201,11 @@ int rebuild_bvh_layout()
 {
     HIPCHK(hipMemsetAsync(g.err, 0, sizeof(int), g.stream));
     if (g.nodeCount) {
-        HIPCHK(hipMemsetAsync(g.hotSlot, 0xFF, ((size_t)g.nodeCount / 2 + 1) * sizeof(uint32_t), g.stream));
-        if (g.numRoots) {
-            uint32_t perMesh = 1;
-            while (perMesh * 2 * g.numRoots <= (uint32_t)CRT_HOT_PAIRS) perMesh *= 2;
-            if (perMesh * g.numRoots > (uint32_t)CRT_HOT_PAIRS) perMesh = 0;
-            if (getenv("CRT_NO_HOT")) perMesh = 0;      // experiment: no top-of-tree packing
-            crt_assign_hot_slots<<<(g.numRoots + 63) / 64, 64, 0, g.stream>>>(g.rawNodes, g.nodeCount, g.roots, g.numRoots, perMesh, g.hotSlot);
-            HIPCHK(hipGetLastError());
-        }
-        crt_relayout_nodes<<<(g.nodeCount + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.pairs, g.bigLeaf, g.hotSlot, g.err);
+        crt_relayout_nodes<<<(g.nodeCount + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.pairs, g.bigLeaf, g.err);
         HIPCHK(hipGetLastError());
     }
-    if (g.numRoots) {
-        crt_make_root_refs<<<(g.numRoots + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.roots, g.numRoots, g.rootRefs, g.bigLeaf, g.hotSlot, g.err);
-        HIPCHK(hipGetLastError());
-    }
+    crt_make_root_refs<<<(CRT_MAX_MESHES + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.roots, g.numRoots, g.rootRefs, g.bigLeaf, g.err);
+    HIPCHK(hipGetLastError());
     int err = 0;
     HIPCHK(hipMemcpyAsync(&err, g.err, sizeof(int), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -471,12 +459,11 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.rawNodes, g.nodeCap * sizeof(CrtBVHNode)));
     HIPCHK(hipMalloc(&g.roots, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.rawTexels, g.texelByteCap + 16));
-    HIPCHK(hipMalloc(&g.pairs, (g.nodeCap / 2 + 1 + CRT_HOT_PAIRS) * 4 * sizeof(float4)));
-    HIPCHK(hipMalloc(&g.hotSlot, (g.nodeCap / 2 + 1) * sizeof(uint32_t)));
-    HIPCHK(hipMemset(g.pairs, 0, (size_t)CRT_HOT_PAIRS * 4 * sizeof(float4)));
+    HIPCHK(hipMalloc(&g.pairs, (g.nodeCap / 2 + 1) * 4 * sizeof(float4)));
     HIPCHK(hipMalloc(&g.triHot, g.triCap * 9 * sizeof(float)));
     HIPCHK(hipMalloc(&g.triCold, g.triCap * 2 * sizeof(uint4)));
-    HIPCHK(hipMalloc(&g.bigLeaf, g.triCap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.bigLeaf, (g.triCap + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMemset(g.bigLeaf + g.triCap, 0, sizeof(uint32_t)));      // crt_empty_ref: a leaf of zero triangles
     HIPCHK(hipMalloc(&g.rootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
@@ -496,7 +483,7 @@ static int init_impl(int device, int width, int height)
     { const char* e = getenv("CRT_TLAS"); g.forceTlas = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
-    HIPCHK(hipMemset(g.rootRefs, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
+    { std::vector<uint32_t> e(CRT_MAX_MESHES, crt_empty_ref((uint32_t)g.triCap)); HIPCHK(hipMemcpy(g.rootRefs, e.data(), e.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); }
     HIPCHK(hipMemset(g.materials, 0, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMemset(g.textures, 0, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMemset(g.texels, 0, 64));
@@ -518,7 +505,7 @@ static void release_all()
 {
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.hotSlot, g.materials, g.textures, g.rays, g.counters, g.err,
+                     g.texels, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount };
     for (FrameSlot& fs : g.slot) {
         void* q[] = { fs.out, fs.ovf, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };

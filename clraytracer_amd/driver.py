@@ -47,6 +47,7 @@ class Session:
     def load_scene(self, scene, device_bvh_build=False):
         h = self.h
         h.crth_set_device_bvh_build(1 if device_bvh_build else 0)   # BuildBVH on the GPU (same bytes as the host build)
+        h.crth_set_asset_root((scene.asset_root or "").encode())
         h.crth_prepare_meshes()
         tex = h.crth_import_texture(scene.skybox.encode())   # must be texture index 2 (Engine.cpp:60-61)
         self._check("ImportTexture(skybox)")

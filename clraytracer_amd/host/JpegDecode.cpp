@@ -141,8 +141,8 @@ struct Decoder {
         const int t = symbol(dc[c.td]);
         if (t < 0 || t > 15) return fail("bad huffman code");
         std::memset(blk, 0, 64 * sizeof(int16_t));
-        c.dcPred += receiveExtend(t);
-        blk[0] = (int16_t)(c.dcPred * q[0]);
+        c.dcPred = (int)((uint32_t)c.dcPred + (uint32_t)receiveExtend(t));      // modulo 2^32, like the rest (damaged files)
+        blk[0] = (int16_t)((uint32_t)c.dcPred * (uint32_t)q[0]);
         for (int k = 1; k < 64;) {
             const int rs = symbol(ac[c.ta]);
             if (rs < 0) return fail("bad huffman code");
@@ -162,8 +162,8 @@ struct Decoder {
             std::memset(blk, 0, 64 * sizeof(int16_t));
             const int t = symbol(dc[c.td]);
             if (t < 0 || t > 15) return fail("bad huffman code");
-            c.dcPred += receiveExtend(t);
-            blk[0] = (int16_t)(c.dcPred * (1 << succLow));
+            c.dcPred = (int)((uint32_t)c.dcPred + (uint32_t)receiveExtend(t));
+            blk[0] = (int16_t)((uint32_t)c.dcPred << succLow);
         } else if (bit()) blk[0] = (int16_t)(blk[0] + (int16_t)(1 << succLow));
         return true;
     }
@@ -440,21 +440,26 @@ struct Decoder {
 };
 
 // ---- inverse DCT (pinned arithmetic) ----
-struct Idct1D { int e0, e1, e2, e3, o0, o1, o2, o3; };
-inline Idct1D idct1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+// All sums and products are taken modulo 2^32 (unsigned), which is what the reference's `int` arithmetic does on every
+// real file and what two's-complement hardware does when a damaged file overflows it -- without undefined behaviour here.
+typedef uint32_t u32;
+inline u32 mulc(u32 a, int c) { return a * (u32)c; }
+inline int sar(u32 x, int n) { return (int)x >> n; }             // arithmetic shift of the two's-complement value
+struct Idct1D { u32 e0, e1, e2, e3, o0, o1, o2, o3; };
+inline Idct1D idct1d(u32 s0, u32 s1, u32 s2, u32 s3, u32 s4, u32 s5, u32 s6, u32 s7)
 {
     Idct1D r;
-    const int z = (s2 + s6) * 2217;
-    const int evenB = z + s6 * -7567, evenA = z + s2 * 3135;
-    const int sum = (s0 + s4) * 4096, dif = (s0 - s4) * 4096;
+    const u32 z = mulc(s2 + s6, 2217);
+    const u32 evenB = z + mulc(s6, -7567), evenA = z + mulc(s2, 3135);
+    const u32 sum = mulc(s0 + s4, 4096), dif = mulc(s0 - s4, 4096);
     r.e0 = sum + evenA; r.e3 = sum - evenA; r.e1 = dif + evenB; r.e2 = dif - evenB;
-    const int a = s7 + s3, b = s5 + s1, c = s7 + s1, d = s5 + s3;
-    const int w = (a + b) * 4816;
-    const int c5 = w + c * -3685, d5 = w + d * -10497, a3 = a * -8034, b3 = b * -1597;
-    r.o3 = s1 * 6149 + (c5 + b3);
-    r.o2 = s3 * 12586 + (d5 + a3);
-    r.o1 = s5 * 8410 + (d5 + b3);
-    r.o0 = s7 * 1223 + (c5 + a3);
+    const u32 a = s7 + s3, b = s5 + s1, c = s7 + s1, d = s5 + s3;
+    const u32 w = mulc(a + b, 4816);
+    const u32 c5 = w + mulc(c, -3685), d5 = w + mulc(d, -10497), a3 = mulc(a, -8034), b3 = mulc(b, -1597);
+    r.o3 = mulc(s1, 6149) + (c5 + b3);
+    r.o2 = mulc(s3, 12586) + (d5 + a3);
+    r.o1 = mulc(s5, 8410) + (d5 + b3);
+    r.o0 = mulc(s7, 1223) + (c5 + a3);
     return r;
 }
 inline unsigned char clamp255(int x) { return (unsigned char)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
@@ -463,21 +468,21 @@ void idctBlock(const int16_t* d, unsigned char* out, int stride)
 {
     int tmp[64];
     for (int c = 0; c < 8; ++c) {
-        const Idct1D r = idct1d(d[c], d[8 + c], d[16 + c], d[24 + c], d[32 + c], d[40 + c], d[48 + c], d[56 + c]);
-        tmp[c] = (r.e0 + 512 + r.o3) >> 10;      tmp[56 + c] = (r.e0 + 512 - r.o3) >> 10;
-        tmp[8 + c] = (r.e1 + 512 + r.o2) >> 10;  tmp[48 + c] = (r.e1 + 512 - r.o2) >> 10;
-        tmp[16 + c] = (r.e2 + 512 + r.o1) >> 10; tmp[40 + c] = (r.e2 + 512 - r.o1) >> 10;
-        tmp[24 + c] = (r.e3 + 512 + r.o0) >> 10; tmp[32 + c] = (r.e3 + 512 - r.o0) >> 10;
+        const Idct1D r = idct1d((u32)d[c], (u32)d[8 + c], (u32)d[16 + c], (u32)d[24 + c], (u32)d[32 + c], (u32)d[40 + c], (u32)d[48 + c], (u32)d[56 + c]);
+        tmp[c] = sar(r.e0 + 512 + r.o3, 10);      tmp[56 + c] = sar(r.e0 + 512 - r.o3, 10);
+        tmp[8 + c] = sar(r.e1 + 512 + r.o2, 10);  tmp[48 + c] = sar(r.e1 + 512 - r.o2, 10);
+        tmp[16 + c] = sar(r.e2 + 512 + r.o1, 10); tmp[40 + c] = sar(r.e2 + 512 - r.o1, 10);
+        tmp[24 + c] = sar(r.e3 + 512 + r.o0, 10); tmp[32 + c] = sar(r.e3 + 512 - r.o0, 10);
     }
-    const int bias = 65536 + (128 << 17);
+    const u32 bias = 65536u + (128u << 17);
     for (int y = 0; y < 8; ++y) {
         const int* v = tmp + y * 8;
         unsigned char* o = out + (size_t)y * stride;
-        const Idct1D r = idct1d(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-        o[0] = clamp255((r.e0 + bias + r.o3) >> 17); o[7] = clamp255((r.e0 + bias - r.o3) >> 17);
-        o[1] = clamp255((r.e1 + bias + r.o2) >> 17); o[6] = clamp255((r.e1 + bias - r.o2) >> 17);
-        o[2] = clamp255((r.e2 + bias + r.o1) >> 17); o[5] = clamp255((r.e2 + bias - r.o1) >> 17);
-        o[3] = clamp255((r.e3 + bias + r.o0) >> 17); o[4] = clamp255((r.e3 + bias - r.o0) >> 17);
+        const Idct1D r = idct1d((u32)v[0], (u32)v[1], (u32)v[2], (u32)v[3], (u32)v[4], (u32)v[5], (u32)v[6], (u32)v[7]);
+        o[0] = clamp255(sar(r.e0 + bias + r.o3, 17)); o[7] = clamp255(sar(r.e0 + bias - r.o3, 17));
+        o[1] = clamp255(sar(r.e1 + bias + r.o2, 17)); o[6] = clamp255(sar(r.e1 + bias - r.o2, 17));
+        o[2] = clamp255(sar(r.e2 + bias + r.o1, 17)); o[5] = clamp255(sar(r.e2 + bias - r.o1, 17));
+        o[3] = clamp255(sar(r.e3 + bias + r.o0, 17)); o[4] = clamp255(sar(r.e3 + bias - r.o0, 17));
     }
 }
 

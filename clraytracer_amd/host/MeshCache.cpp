@@ -148,7 +148,7 @@ ObjMesh* AssetManager_LoadMeshFromDisk(const char* path, Tri* triArena, size_t m
     auto fail = [&](const char* why) { std::fprintf(stderr, "[AssetManager] %s: %s\n", path, why); return (ObjMesh*)nullptr; };
     if (!readOk) return fail("cannot read mesh cache");
     size_t at = 0;
-    auto take = [&](void* out, size_t n) { if (at + n > file.size()) return false; std::memcpy(out, file.data() + at, n); at += n; return true; };
+    auto take = [&](void* out, size_t n) { if (n > file.size() - at) return false; std::memcpy(out, file.data() + at, n); at += n; return true; };
     unsigned version = 0, msz = 0; int numTris = 0, numMaterials = 0;
     if (!take(&version, 4) || !take(&numTris, 4) || !take(&numMaterials, 4)) return fail("truncated mesh cache");
     if (version != CMeshVersion) return fail("mesh version is not same!");           // AssetManager.cpp:341 (exit(0) upstream)
@@ -171,7 +171,8 @@ ObjMesh* AssetManager_LoadMeshFromDisk(const char* path, Tri* triArena, size_t m
     if (ok && numTris < 1000) ok = take(triArena, bytes);
     else if (ok) {
         unsigned long long comp = 0;
-        ok = take(&comp, 8) && at + comp <= file.size()
+        // `comp` is an untrusted 64-bit field: compare against what is left of the file (at <= file.size() after take), never at + comp
+        ok = take(&comp, 8) && comp <= (unsigned long long)(file.size() - at)
              && MeshCache_QlzDecompress(file.data() + at, (size_t)comp, reinterpret_cast<unsigned char*>(triArena), bytes) == bytes;
     }
     if (!ok) { AssetManager_DestroyMesh(mesh); return fail("corrupt mesh cache"); }

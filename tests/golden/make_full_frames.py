@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Known answers at BASELINE.json's full sizes, from the CPU ORACLE (never from the HIP path): SHA-256 of the 1920x1080
 pre-PostProcess float frame, of the shadow-extension frame and of the RGBA8 (hazard H8) bytes, plus the work counters,
-for the four synthetic scenes -> tests/golden/full_frames.json. Run from the repo root (about a minute on 8 cores):
+for the synthetic scenes and the two scenes made of the reference's shipped assets -> tests/golden/full_frames.json. Run from the repo root (about a minute on 8 cores):
     python tests/golden/make_full_frames.py
-The scenes are generated from seeds (clraytracer_amd/scenes.py), so the fixture is machine-independent."""
+The scenes are generated from seeds (clraytracer_amd/scenes.py) or loaded from tests/golden/assets, so the fixture is
+machine-independent."""
 import hashlib
 import json
 import os
@@ -29,7 +30,7 @@ def sha(a):
 def main():
     out = {}
     w, h = 1920, 1080
-    for name in ("tiny", "cornell-1k", "sponza-class-250k", "multi-1M"):
+    for name in ("tiny", "cornell-1k", "sponza-class-250k", "multi-1M", "multi-1M-dense", "sponza-sibenik", "nanosuit-demo"):
         sc = scenes.get(name)
         with driver.Session(w, h, host_only=True) as s:
             s.load_scene(sc)

@@ -1,7 +1,10 @@
 """BASELINE.json configs 2-5 on the GPU at their full sizes, against the CPU oracle.
 
 config 2: cornell-1k 1920x1080 | config 3: sponza-class-250k 1920x1080 | config 4: multi-1M 1920x1080
-config 5: multi-1M 3840x2160 rendered as 8 row-band ranks on one GPU, stitched, vs the single-rank frame.
+config 5: multi-1M 3840x2160 rendered as 8 row-band ranks on one GPU, stitched, vs the single-rank frame (test_gpu_config5.py).
+Beyond BASELINE's list: multi-1M-dense (config 4 seen from among its instances: 97 % of the primary rays hit) and the two
+scenes built from the reference's own shipped assets with their JPEG textures, sponza-sibenik and nanosuit-demo
+(clraytracer_amd/scenes.py; Engine.cpp:56-80 is upstream's demo of the same kind).
 Tolerances as in test_gpu_parity.py (RMSE < 1e-4 pre-PostProcess; hit records and counters exact).
 """
 import numpy as np
@@ -14,7 +17,7 @@ from util import bits, rmse, seeded_rays
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["cornell-1k", "sponza-class-250k", "multi-1M"])
+@pytest.fixture(scope="module", params=["cornell-1k", "sponza-class-250k", "multi-1M", "multi-1M-dense", "sponza-sibenik", "nanosuit-demo"])
 def full(request, nthreads):
     sc = scenes.get(request.param)
     s = driver.Session(1920, 1080, device=0)
