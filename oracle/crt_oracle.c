@@ -513,6 +513,14 @@ void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* r
 void orc_closest_hits(const OrcScene* s, const float* origins, const float* dirs, int n,
                       CrtRayHit* out, OrcStats* stats, int nthreads)
 {
+    orc_closest_hits_ex(s, origins, dirs, n, out, stats, nthreads, NULL);
+}
+
+/* As orc_closest_hits; `capped` (optional, n bytes) is set to 1 for every ray whose traversals hit the 250-pop cap
+ * (kernel_main.cl:131) in some instance, i.e. whose result may depend on where the traversal was cut off. */
+void orc_closest_hits_ex(const OrcScene* s, const float* origins, const float* dirs, int n,
+                         CrtRayHit* out, OrcStats* stats, int nthreads, uint8_t* capped)
+{
     if (nthreads < 1) nthreads = 1;
     OrcStats total; memset(&total, 0, sizeof total);
 #pragma omp parallel num_threads(nthreads)
@@ -523,7 +531,9 @@ void orc_closest_hits(const OrcScene* s, const float* origins, const float* dirs
             Ray ray = { f3_make(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]),
                         f3_make(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]) };
             st.rays++;
+            const uint64_t capsBefore = st.capHits;
             Closest c = closest_hit(s, ray, s->numInstances, &st);
+            if (capped) capped[k] = st.capHits != capsBefore;
             CrtRayHit h;
             if (c.anyHit) {
                 h.t = c.hitOut.t; h.u = c.hitOut.u; h.v = c.hitOut.v;

@@ -124,6 +124,9 @@ void orc_set_visit_counts(uint32_t* counts);
 /* Closest-hit query for arbitrary world-space rays: the instance loop of kernel_main.cl:198-217. */
 void orc_closest_hits(const OrcScene* s, const float* origins, const float* dirs, int n,
                       CrtRayHit* out, OrcStats* stats, int nthreads);
+/* The same, also flagging (capped[k] = 1) the rays whose traversal hit the 250-pop cap; `capped` may be NULL. */
+void orc_closest_hits_ex(const OrcScene* s, const float* origins, const float* dirs, int n,
+                         CrtRayHit* out, OrcStats* stats, int nthreads, uint8_t* capped);
 /* CPU_RayCast (CPURayTrace.cpp:186-249), with _mm_rcp_ps pinned to IEEE 1/x. */
 void orc_cpu_raycast(const OrcScene* s, const float* origins, const float* dirs, int n,
                      CrtHitRecord* out, int nthreads);

@@ -12,7 +12,7 @@ from clraytracer_amd import _lib, driver, scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libquicklz_ref.so")
-REF_ASSETS = "/root/reference/CLRayTracer/Assets"
+REF_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets", "Assets")   # the caches upstream ships, committed as data fixtures
 
 
 def qlz_decompress(data, out_len):
@@ -69,7 +69,6 @@ def test_decoder_against_the_reference_codec():
             assert qlz_decompress(comp.raw[:n // 2], len(raw))[0] in (0,)
 
 
-@pytest.mark.skipif(not os.path.isdir(REF_ASSETS), reason="the reference's shipped .clm caches are only available where the reference tree is mounted")
 @pytest.mark.parametrize("rel,min_tris", [("sphere.clm", 80), ("sponza/sponza.clm", 66447), ("sibenik/sibenik.clm", None), ("nanosuit/nanosuit.clm", None)])
 def test_loads_upstream_mesh_caches(rel, min_tris, tmp_path):
     """The caches upstream ships (QuickLZ-compressed above 1000 triangles) load through the mirrored importer: they
@@ -83,8 +82,8 @@ def test_loads_upstream_mesh_caches(rel, min_tris, tmp_path):
         import struct
         want_tris, want_mats = struct.unpack_from("<ii", open(src, "rb").read(12), 4)
         handle = h.crth_import_mesh(str(tmp_path / (stem + ".obj")).encode())
-        # (the MTL text names JPEG textures, which this build does not decode: those imports fail and fall back to the
-        #  default texture -- the mesh itself must be there)
+        # (no asset root is set here, so the JPEG textures the MTL text names are not found: those imports fail and fall
+        #  back to the default texture -- the mesh itself must be there; tests/test_jpeg.py covers the textured import)
         info = np.zeros(4, np.uint32)
         h.crth_mesh_info(handle, info.ctypes.data)
         assert info[0] == want_tris and info[3] == want_mats and (min_tris is None or info[0] == min_tris)
@@ -131,3 +130,59 @@ def test_cache_written_on_import_and_preferred_afterwards(level, tmp_path):
         s.h.crth_import_mesh(obj.encode())
         assert s.h.crth_last_error() == 0
         assert _lib.as_array(s.h.crth_triangles(), s.h.crth_num_triangles(), _lib.TRI_DTYPE).tobytes() == first.tobytes()
+
+
+FIXTURE_CLMS = ["sponza/sponza.clm", "sibenik/sibenik.clm", "nanosuit/nanosuit.clm"]
+FIXTURE_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets", "Assets")
+
+
+def _clm_stream(blob):
+    """-> (numTris, offset of the QuickLZ stream, its length) of a .clm with >= 1000 triangles (AssetManager.cpp:294-361)."""
+    import struct
+    version, nt, nm = struct.unpack_from("<Iii", blob, 0)
+    assert version == 0 and nt >= 1000
+    at = 12 + 24 * nm
+    msz, = struct.unpack_from("<I", blob, at)
+    at += 4 + msz
+    comp, = struct.unpack_from("<Q", blob, at)
+    return nt, at + 8, comp
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libquicklz_ref.so is only built where the reference tree is mounted")
+@pytest.mark.parametrize("rel", FIXTURE_CLMS)
+def test_shipped_caches_decode_like_the_reference_codec(rel):
+    """The QuickLZ streams inside the caches upstream ships -- the only reference-held data of the mesh path -- decoded by
+    the product's decoder and by the reference's own quicklz.c (compiled as it lies): identical bytes."""
+    R = C.CDLL(REF_SO)
+    R.qlz_get_setting.restype = C.c_int
+    R.qlz_decompress.restype = C.c_size_t
+    R.qlz_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    R.qlz_size_decompressed.restype = C.c_size_t
+    R.qlz_size_decompressed.argtypes = [C.c_void_p]
+    blob = open(os.path.join(FIXTURE_ASSETS, rel), "rb").read()
+    nt, at, comp = _clm_stream(blob)
+    stream = blob[at:at + comp]
+    assert len(stream) == comp and R.qlz_size_decompressed(stream) == nt * 80
+    state = C.create_string_buffer(R.qlz_get_setting(2))
+    ref = C.create_string_buffer(nt * 80)
+    assert R.qlz_decompress(stream, ref, state) == nt * 80
+    n, got = qlz_decompress(stream, nt * 80)
+    assert n == nt * 80 and got.tobytes() == ref.raw
+    tris = np.frombuffer(ref.raw, _lib.TRI_DTYPE)
+    assert np.isfinite(tris["v0"]).all() and np.isfinite(tris["v1"]).all() and np.isfinite(tris["v2"]).all()
+
+
+def test_cache_with_a_lying_length_field_is_refused(tmp_path):
+    """The 64-bit compressed-size field is untrusted: a value near 2^64 must not wrap the bounds check."""
+    import struct
+    blob = bytearray(open(os.path.join(FIXTURE_ASSETS, "nanosuit", "nanosuit.clm"), "rb").read())
+    nt, at, comp = _clm_stream(bytes(blob))
+    for lie in (2 ** 64 - 1, 2 ** 64 - (at - 4), len(blob), comp + 1):
+        bad = bytearray(blob)
+        struct.pack_into("<Q", bad, at - 8, lie)
+        p = tmp_path / "liar.clm"
+        p.write_bytes(bad)
+        with driver.Session(64, 48, host_only=True) as s:
+            s.h.crth_prepare_meshes()
+            s.h.crth_import_mesh(str(tmp_path / "liar.obj").encode())
+            assert s.h.crth_last_error() != 0 and s.h.crth_num_triangles() == 0
