@@ -20,11 +20,21 @@ Rays = primary rays + secondary rays actually traced, counted on the device by a
 launch outside the timed region (and checked against the oracle in tests/).
 
 The JSON line also carries
-  roofline     : algorithmic HBM bytes of the dominant kernel (crt_trace_kernel) per launch
-                 (64 B x inner visits + 48 B x triangle tests + 80 B x instance records
-                 + fixed per-hit / per-miss / per-pixel bytes) / its mean HIP-event duration, vs 8 TB/s.
-  cpu_baseline : the CPU oracle (oracle/, a port of the reference kernels) tracing one full frame of
-                 the same workload on this box's host cores (rank 0, N == 1 only).
+  roofline     : the dominant kernel (crt_trace_kernel) against the HBM roofline the way it can be true:
+                 `achieved` = HBM-side bytes per launch MEASURED by the committed PMC passes of this same command
+                 (profiles/*_summary.json: FETCH_SIZE + WRITE_SIZE, per launch) / the kernel's device time per launch
+                 from HIP events, `peak` = 8 TB/s, `frac` = achieved / peak (<= 1 by construction; null when no PMC
+                 profile of this workload is committed). SURVEY.md 8d's layout-independent ALGORITHMIC bytes (64 B x
+                 inner visits + 48 B x triangle tests + 80 B x instance records + fixed per-hit / per-miss / per-pixel
+                 bytes) are reported next to it as `algorithmic_*`: they exceed what reaches HBM many times over (the
+                 hot data sits in L1/L2/Infinity Cache), so their rate is not a fraction of any roofline.
+                 `gather` is the bound that does hold for this kernel: real (post-cull) 64-B child-pair fetches per
+                 cycle per CU against the microbenchmarked ceiling for divergent 64-B gathers served from L2
+                 (tools/ubench/gather.hip, profiles/r01_ubench_gather.txt).
+  cpu_baseline : the reference's CPU path timed on this box's host cores (rank 0, N == 1 only): the mirrored
+                 CPU_RayCast (CPURayTrace.cpp:186-249, SSE flavour with upstream's rcpps/dpps instruction mix) over the
+                 primary rays of the bench frame at 1 thread and at all usable cores, and the scalar Trace oracle
+                 (both bounces) on the same frame.
 """
 import argparse
 import json
@@ -47,10 +57,37 @@ def algorithmic_bytes(c, pixels):
     return per_ray + per_hit + per_miss + per_pixel
 
 
+# tools/ubench/gather.hip on MI355X (profiles/r01_ubench_gather.txt): fully divergent 64-B-per-lane gathers, table
+# resident in L2: 181 cycles per wave-level fetch of 64 records per CU -> 0.354 records per cycle per CU
+GATHER_CEILING_L2 = 64.0 / 181.0
+
+
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives one GPU's share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 COUNTER_KEYS = ["rays", "primary", "secondary", "hits", "misses", "traversals", "pops", "innerVisits", "triTests", "shadowRays"]
 
 
-def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device):
+def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device, group=None):
     """Whole-job totals: SUM of the per-rank work counters / pixels / algorithmic bytes, MAX of the per-rank times.
     `dist` is torch.distributed (initialised) or None for a single process. No pixel data is exchanged."""
     import torch
@@ -58,8 +95,8 @@ def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device):
                        dtype=torch.float64, device=device)
     tmax = torch.tensor([float(elapsed_s), float(kernel_ms_mean)], dtype=torch.float64, device=device)
     if dist is not None:
-        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     tot = dict(zip(COUNTER_KEYS + ["pixels", "alg_bytes"], vec.tolist()))
     return tot, tmax[0].item(), tmax[1].item()
 
@@ -116,6 +153,7 @@ def main():
     flight = max(1, min(4, args.frames_in_flight))
     os.environ["CRT_FRAMES_IN_FLIGHT"] = str(flight)   # read by crt_init
 
+    import ctypes as C
     import numpy as np
     import torch
     from clraytracer_amd import _lib, driver, scenes
@@ -127,28 +165,40 @@ def main():
     rehearse = os.environ.get("CRT_BENCH_REHEARSE") == "1"
     device_index = 0 if rehearse else local_rank
     torch.cuda.set_device(device_index)
-    red_device = "cpu" if rehearse else "cuda"
+    red_device = "cpu"
     dist = None
+    ctl = None              # process group for barriers/reductions (None = the default gloo group)
+    control_plane = None
     if n > 1 or os.environ.get("CRT_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise the RCCL control plane with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:                                  # CRT_BENCH_FORCE_DIST without a launcher
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
                 os.environ.setdefault(k, v)
-        if rehearse:
-            dist.init_process_group(backend="gloo")
-        else:
-            # RCCL only carries the barrier and two tiny reductions (no pixel data crosses GPUs). If it cannot come up
-            # on this node, the same control plane runs over gloo: the measurement itself is unaffected.
+        # The control plane is ONE process group created the same way on every rank: gloo over TCP (always available). RCCL
+        # only ever carried a barrier and two tiny reductions here (no pixel data crosses GPUs), so whether it comes up is
+        # decided COLLECTIVELY: every rank tries to create an nccl (= RCCL) sub-group and to reduce one value through it,
+        # the outcomes are MIN-reduced over gloo, and only if all ranks succeeded do barriers/reductions use RCCL. (Round
+        # 1 fell back per rank inside an `except`, which deadlocks when only some ranks fail.)
+        dist.init_process_group(backend="gloo")
+        ctl = None
+        if not rehearse and os.environ.get("CRT_BENCH_BACKEND", "nccl") == "nccl":
+            ok = 1
             try:
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                dist.barrier()
+                ctl = dist.new_group(backend="nccl")
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe, group=ctl)
+                torch.cuda.synchronize()
+                ok = int(probe.item() == world)
             except Exception as e:  # pragma: no cover - depends on the node
-                sys.stderr.write(f"[bench] RCCL control plane unavailable ({e}); using gloo\n")
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group(backend="gloo")
-                red_device = "cpu"
+                sys.stderr.write(f"[bench] rank {rank}: RCCL group unavailable ({e})\n")
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                ctl = None
+        red_device = "cuda" if ctl is not None else "cpu"
+        control_plane = "rccl" if ctl is not None else "gloo"
 
     width = args.width or (1920 if n == 1 else 3840)
     height = args.height or (1080 if n == 1 else 2160)
@@ -156,7 +206,7 @@ def main():
     if rank == 0:
         sc = scenes.get(args.scene)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=ctl)
     if rank != 0:
         sc = scenes.get(args.scene)
 
@@ -169,16 +219,18 @@ def main():
     # instrumented launch (untimed): rays and work counters of this rank's share of the frame
     s.render_raw(8 | (32 if args.shadows else 0))
     cnt = s.counters()
+    culled = C.c_uint64()
+    _lib.check(_lib.hip().crt_get_culled_visits(C.byref(culled)), "crt_get_culled_visits")
+    pair_fetches = cnt["innerVisits"] - int(culled.value)        # child-pair records the device really fetches per frame
     own_rows = s.owned_rows()
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
     # static camera: build the C arguments once so the timed loop is one C call per frame
-    import ctypes as C
     targs, iv, ip = s.trace_args()
     fp = C.POINTER(C.c_float)
     p_args, p_iv, p_ip = C.byref(targs), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp)
@@ -236,21 +288,50 @@ def main():
         sync_elapsed = time.perf_counter() - t0
         _lib.check(rc, "crt_render")
 
-    tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, extent_ms, red_device)
+    # N > 1: the same K frames with every rank's bands DELIVERED per frame -- copied to pinned host memory behind the
+    # frame's kernels (CRT_RENDER_READBACK moves only the rows a rank owns), the last copy complete before the clock
+    # stops. The headline above leaves the tiles in each rank's HBM; this is the rate at which a whole frame reaches
+    # one place (host memory of the node) that a consumer can read.
+    deliver_elapsed = None
+    if n > 1:
+        dflags = flags | 128
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        for _ in range(min(args.warmup, 3)):
+            _lib.check(crt_render(p_args, p_iv, p_ip, dflags), "crt_render")
+        _lib.check(hip.crt_map_host_frame(C.byref(ptr), C.byref(nbytes)), "crt_map_host_frame")
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rc = crt_render(p_args, p_iv, p_ip, dflags)
+        rc2 = hip.crt_map_host_frame(C.byref(ptr), C.byref(nbytes))      # waits for the last frame's copy
+        rc3 = hip.crt_sync()
+        barrier()
+        deliver_elapsed = time.perf_counter() - t0
+        _lib.check(rc, "crt_render"); _lib.check(rc2, "crt_map_host_frame"); _lib.check(rc3, "crt_sync")
+
+    tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, extent_ms, red_device, ctl)
     if sync_elapsed is not None:
-        _, sync_elapsed, _ = aggregate(dist, cnt, own_rows * width, sync_elapsed, 0.0, red_device)
+        _, sync_elapsed, _ = aggregate(dist, cnt, own_rows * width, sync_elapsed, 0.0, red_device, ctl)
+    if deliver_elapsed is not None:
+        _, deliver_elapsed, _ = aggregate(dist, cnt, own_rows * width, deliver_elapsed, 0.0, red_device, ctl)
 
     if rank == 0:
         rays_per_frame = tot["rays"]
         ms_per_step = elapsed_max * 1e3 / args.steps
         value = rays_per_frame * args.steps / elapsed_max / 1e6
-        # roofline of the dominant kernel on this rank (per launch = this rank's share of one frame)
+        # ---- roofline of the dominant kernel on this rank (per launch = this rank's share of one frame) ----
+        # device time per launch = extent of the timed region on the launch streams / K (HIP events). With one frame in
+        # flight that is the launch duration; with frames in flight launches overlap, each lasts longer
+        # (launch_duration_ms, what a kernel trace shows) and shares the machine with the others.
         my_bytes = algorithmic_bytes(cnt, own_rows * width)
-        # GPU-level rate: bytes of one launch / device time per launch (extent of the timed region / K). With one frame
-        # in flight that is the launch duration itself; with frames in flight launches overlap, each one lasts longer
-        # (launch_duration_ms, the figure a kernel trace shows) and shares the machine with the others.
-        achieved = my_bytes / (extent_ms * 1e-3) / 1e9
+        dev_s = extent_ms * 1e-3
         traffic, traffic_src = pmc_traffic("crt_trace_kernel", sc.name, width, height) if (n == 1 and not args.shadows) else (None, None)
+        achieved = None if traffic is None else traffic / dev_s / 1e9
+        frac = None if achieved is None else achieved / HBM_PEAK_GBS
+        assert frac is None or frac <= 1.0, f"measured HBM traffic rate {achieved} GB/s exceeds the peak: profile does not belong to this run"
+        clock_ghz = float(os.environ.get("CRT_SCLK_GHZ", "2.4"))             # MI355X peak engine clock (MI355X_MICROARCH.md)
+        num_cus = int(hip.crt_device_name().decode().split(",")[-1].split()[0])
+        gather_rate = pair_fetches / (dev_s * clock_ghz * 1e9 * num_cus)       # 64-B records per cycle per CU
         out = {
             "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -260,46 +341,83 @@ def main():
                                    f"{width}x{height}, primary + 1 reflection bounce" + (" + 1 shadow ray per lit first hit (extension)" if args.shadows else "") + ", RayGen fused",
                        "scene": sc.name, "width": width, "height": height, "rays_per_frame": int(rays_per_frame),
                        "primary": int(tot["primary"]), "secondary": int(tot["secondary"]), "shadow": int(tot["shadowRays"]),
+                       "primary_hit_fraction": round(tot["secondary"] / max(1.0, tot["primary"]), 4),
                        "tiling": f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
-                       "frames_in_flight": flight,
+                       "frames_in_flight": flight, "control_plane": control_plane,
                        "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2)},
+            "inner_visits_per_s": round(tot["innerVisits"] * args.steps / elapsed_max, 0),
+            "tri_tests_per_s": round(tot["triTests"] * args.steps / elapsed_max, 0),
             "kernel_ms": {"crt_trace_kernel_launch_mean": round(launch_ms, 4), "device_time_per_frame": round(extent_ms, 4),
                           "frame_latency_mean": round(stats.sumMs[0] / max(1, stats.frames), 4),
                           "device_time_per_frame_max_over_ranks": round(kernel_ms_max, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "crt_trace_kernel<COUNT=false, STAMP=false, SHADOW=%s, WIDE=per frame, TLAS=false>" % ("true" if args.shadows else "false"), "algorithmic_bytes_per_launch": int(my_bytes),
-                         "launch_duration_ms": round(launch_ms, 4), "launches_in_flight": flight,
-                         "achieved_per_launch": round(my_bytes / (launch_ms * 1e-3) / 1e9, 2),
+            "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if frac is None else round(frac, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved_definition": "PMC-measured FETCH_SIZE + WRITE_SIZE bytes per launch / device time per launch",
+                         "kernel": "crt_trace_kernel<COUNT=false, STAMP=false, SHADOW=%s, TLAS=false>" % ("true" if args.shadows else "false"),
+                         "launch_duration_ms": round(launch_ms, 4), "launches_in_flight": flight, "device_time_per_launch_ms": round(extent_ms, 4),
+                         "algorithmic_bytes_per_launch": int(my_bytes),
+                         "algorithmic_rate_gbs": round(my_bytes / dev_s / 1e9, 2),
+                         "algorithmic_over_traffic": None if traffic is None else round(my_bytes / traffic, 1),
+                         "algorithmic_note": "SURVEY 8d bytes from reference struct sizes; served from L1/L2/Infinity Cache and removed by the instance cull, "
+                                             "hence far above the HBM traffic and not a fraction of the HBM roofline",
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
                          "inner_visits_per_ray": round(cnt["innerVisits"] / max(1, cnt["rays"]), 2),
-                         "tri_tests_per_ray": round(cnt["triTests"] / max(1, cnt["rays"]), 2)},
+                         "tri_tests_per_ray": round(cnt["triTests"] / max(1, cnt["rays"]), 2),
+                         "gather": {"bound": "divergent 64-B record gathers served from L2, records per cycle per CU (tools/ubench/gather.hip)",
+                                    "pair_fetches_per_launch": int(pair_fetches), "culled_root_visits_per_launch": int(culled.value),
+                                    "achieved": round(gather_rate, 4), "ceiling": round(GATHER_CEILING_L2, 4),
+                                    "frac": round(gather_rate / GATHER_CEILING_L2, 4), "clock_ghz": clock_ghz, "cus": num_cus}},
         }
         if sync_elapsed is not None:
             out["synchronous_frames"] = {"value": round(rays_per_frame * args.steps / sync_elapsed / 1e6, 2), "unit": "Mrays/s",
                                          "ms_per_step": round(sync_elapsed * 1e3 / args.steps, 4),
                                          "note": "same K frames one at a time (the reference's Render() + clFinish), max over ranks"}
+        if deliver_elapsed is not None:
+            out["delivered_to_host"] = {"value": round(rays_per_frame * args.steps / deliver_elapsed / 1e6, 2), "unit": "Mrays/s",
+                                        "ms_per_step": round(deliver_elapsed * 1e3 / args.steps, 4),
+                                        "note": "same K frames, every rank's bands copied to pinned host memory per frame inside the timed region (float4), max over ranks"}
         if single is not None:
             out["single_gpu_same_workload"] = {"value": round(rays_per_frame / single / 1e6, 2), "unit": "Mrays/s",
                                                "ms_per_step": round(single * 1e3, 4), "note": "rank 0 alone rendering the whole frame, 10 frames, same mode"}
         if n == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
-            orc = oracle_lib.Oracle(s.arenas(), nthreads=threads)
+            threads = args.cpu_threads or min(usable_cpus(), 64)
             iv, ip, pos = s.camera()
+            orc = oracle_lib.Oracle(s.arenas(), nthreads=threads)
             rays = orc.raygen(width, height, iv, ip)
+            # (1) the reference's CPU path: CPU_RayCast (CPURayTrace.cpp:186-249) once per pixel of the bench frame -- one
+            # primary ray, closest hit + albedo, no lighting, no bounce. SSE flavour = upstream's rcpps/dpps instruction mix.
+            flat = np.ascontiguousarray(rays.reshape(-1, 3))
+            origins = np.ascontiguousarray(np.tile(np.asarray(pos, np.float32), (len(flat), 1)))
+            sub = slice(0, len(flat), 8)                                  # 1 thread: every 8th ray (bounded to a few seconds)
+            t0 = time.perf_counter(); s.cpu_raycast(origins[sub], flat[sub], nthreads=1, sse=True); dt1 = time.perf_counter() - t0
+            dtn, rec = None, None
+            for _ in range(3):                                            # best of 3 (thread start-up, first touch)
+                t0 = time.perf_counter(); rec = s.cpu_raycast(origins, flat, nthreads=threads, sse=True); d = time.perf_counter() - t0
+                dtn = d if dtn is None else min(dtn, d)
+            hits_cpu = int((rec["distance"] < 1e29).sum())
+            # (2) the scalar Trace oracle: the whole path (both bounces, shading) on the same frame
             t0 = time.perf_counter()
             _, st = orc.trace(rays, pos, sc.sun_angle, shadows=args.shadows)
             dt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                                   "sample": f"one full {width}x{height} frame of the same scene ({st['rays']} rays, {dt:.2f} s wall)",
-                                   "rays_match_gpu": bool(st["rays"] == cnt["rays"])}
+            out["cpu_baseline"] = {
+                "value": round(len(flat) / dtn / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "sample": f"CPU_RayCast (host mirror of CPURayTrace.cpp:186-249, SSE flavour) over the {len(flat)} primary rays of the bench frame "
+                          f"({width}x{height}, {sc.name}), {threads} threads, best of 3: {dtn:.3f} s",
+                "cpu_model": cpu_model(), "logical_cpus": os.cpu_count(), "usable_cpus": usable_cpus(),
+                "cpu_raycast_1_thread": {"value": round(len(flat[sub]) / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                                         "sample": f"every 8th primary ray of the same frame ({len(flat[sub])} rays, {dt1:.2f} s)"},
+                "primary_hits_cpu_vs_gpu": [hits_cpu, int(cnt["secondary"])],
+                "primary_hits_consistent": bool(abs(hits_cpu - cnt["secondary"]) <= 1e-3 * max(1, cnt["secondary"])),
+                "trace_oracle": {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                                 "sample": f"scalar restatement of kernel_main.cl Trace, both bounces, one full frame ({st['rays']} rays, {dt:.2f} s)",
+                                 "rays_match_gpu": bool(st["rays"] == cnt["rays"])}}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     s.close()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=ctl)
         dist.destroy_process_group()
 
 

@@ -87,6 +87,7 @@ HIP_API = {
     "crt_last_kernel_ms": (C.c_float, [C.c_int]),
     "crt_frame_time_stats": (C.c_int, [C.POINTER(CrtFrameStats), C.c_int]),
     "crt_get_counters": (C.c_int, [C.POINTER(CrtCounters)]),
+    "crt_get_culled_visits": (C.c_int, [C.POINTER(C.c_uint64)]),
     "crt_debug_read_stamps": (C.c_int, [_vp, _sz, C.POINTER(C.c_size_t)]),
     "crt_error_string": (C.c_char_p, [C.c_int]),
     "crt_device_name": (C.c_char_p, []),
@@ -132,6 +133,7 @@ HOST_API = {
     "crth_map_output": (_vp, []),
     "crth_last_frame_ms": (C.c_float, []),
     "crth_cpu_raycast": (None, [_vp, _vp, C.c_int, _vp, C.c_int]),
+    "crth_cpu_raycast_sse": (None, [_vp, _vp, C.c_int, _vp, C.c_int]),
     "crth_triangles": (_vp, []), "crth_num_triangles": (_sz, []),
     "crth_nodes": (_vp, []), "crth_num_nodes": (_sz, []),
     "crth_roots": (_vp, []), "crth_num_meshes": (C.c_int, []),

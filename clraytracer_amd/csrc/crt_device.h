@@ -176,6 +176,7 @@ struct LaneCounters {
     uint32_t rays, primary, secondary, hits, misses;
     uint32_t traversals, pops, innerVisits, triTests, capHits, stackOverflows, maxStack;
     uint32_t shadowRays, shadowHits;      // CRT_RENDER_SHADOWS only
+    uint32_t culled;                      // instance visits the sphere cull answered (counted in traversals/pops/innerVisits as upstream's one pop + one root visit)
 };
 
 // kernel_main.cl:108-117
@@ -385,7 +386,7 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
         const bool cull = (bs.w >= 0.0f) && ((oc2 * dd - b * b > r2 * dd) || (b < 0.0f && oc2 > r2));
         if (!cull) cand |= 1ull << k;
     }
-    if (COUNT && !DEFER_COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(cand); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
+    if (COUNT && !DEFER_COUNT) { const uint32_t culled = cnt - (uint32_t)__popcll(cand); lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; lc.culled += culled; }
     return cand;
 }
 
@@ -475,7 +476,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
         const bool fits = tlas_candidates(S, o, d, stack, L);
         if (__ballot(!fits) == 0) {
             int prev = -1;                                        // last instance entered (ANYHIT + COUNT: culled ones in between)
-            if (COUNT && !ANYHIT) { const uint32_t culled = S.numInstances - L.n; lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; }
+            if (COUNT && !ANYHIT) { const uint32_t culled = S.numInstances - L.n; lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; lc.culled += culled; }
             bool done = false;
             for (;;) {
                 const bool wEnter = !done && !T.active;
@@ -490,9 +491,9 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
                         const uint32_t k = (ANYHIT && c.anyHit) ? 0xFFFFu : candidate_list_next(L, prev);
                         if (k == 0xFFFFu) {
                             done = true;
-                            if (COUNT && ANYHIT && !c.anyHit) { const uint32_t n = S.numInstances - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; }
+                            if (COUNT && ANYHIT && !c.anyHit) { const uint32_t n = S.numInstances - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; }
                         } else {
-                            if (COUNT && ANYHIT) { const uint32_t n = k - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; }
+                            if (COUNT && ANYHIT) { const uint32_t n = k - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; }
                             prev = (int)k;
                             T.enter(S, k, o, d, c.distance, lc);
                         }
@@ -526,7 +527,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
                     if (ANYHIT && c.anyHit) done = true;           // occluded: later instances are never visited
                     else if (cand == 0) {                          // this lane is finished with the chunk
                         done = true;
-                        if (COUNT && ANYHIT) { const uint32_t n = (uint32_t)__popcll(culledLeft); lc.traversals += n; lc.pops += n; lc.innerVisits += n; culledLeft = 0; }
+                        if (COUNT && ANYHIT) { const uint32_t n = (uint32_t)__popcll(culledLeft); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; culledLeft = 0; }
                     } else {
                         if (ITERS) { if (first_active_lane()) lc.traversals++; }
                         const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
@@ -534,7 +535,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
                         if (COUNT && ANYHIT) {
                             const unsigned long long below = culledLeft & ((1ull << k) - 1ull);
                             const uint32_t n = (uint32_t)__popcll(below);
-                            lc.traversals += n; lc.pops += n; lc.innerVisits += n; culledLeft &= ~below;
+                            lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; culledLeft &= ~below;
                         }
                         T.enter(S, base + k, o, d, c.distance, lc);
                     }

@@ -27,11 +27,11 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 __device__ __forceinline__ void flush_counters(const LaneCounters& lc, unsigned long long* g)
 {
     // every lane of the wave must call this (inactive pixels contribute zeros)
-    uint32_t s[13] = { lc.rays, lc.primary, lc.secondary, lc.hits, lc.misses, lc.traversals, lc.pops,
-                       lc.innerVisits, lc.triTests, lc.capHits, lc.stackOverflows, lc.shadowRays, lc.shadowHits };
+    uint32_t s[14] = { lc.rays, lc.primary, lc.secondary, lc.hits, lc.misses, lc.traversals, lc.pops,
+                       lc.innerVisits, lc.triTests, lc.capHits, lc.stackOverflows, lc.shadowRays, lc.shadowHits, lc.culled };
     uint32_t mx = wave_max(lc.maxStack);
 #pragma unroll
-    for (int k = 0; k < 13; ++k) {
+    for (int k = 0; k < 14; ++k) {
         uint32_t t = wave_sum(s[k]);
         if ((threadIdx.x & 63) == 0 && t) atomicAdd(&g[k < 11 ? k : k + 1], (unsigned long long)t);   // [11] is maxStack
     }
@@ -42,7 +42,7 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
 {
     lc.rays = lc.primary = lc.secondary = lc.hits = lc.misses = 0;
     lc.traversals = lc.pops = lc.innerVisits = lc.triTests = lc.capHits = lc.stackOverflows = lc.maxStack = 0;
-    lc.shadowRays = lc.shadowHits = 0;
+    lc.shadowRays = lc.shadowHits = 0; lc.culled = 0;
 }
 
 

@@ -92,11 +92,11 @@ struct State {
     double msSum[4] = { 0, 0, 0, 0 }; unsigned long long framesTimed = 0;   // crt_frame_time_stats
     float ms[4] = { 0, 0, 0, 0 }; unsigned long long msSeq = 0, frameSeq = 0;   // timing of the newest frame read back so far
     hipEvent_t statStart = nullptr; bool statStartArmed = true, statStartValid = false; unsigned long long statStartSeq = 0; double statExtent = 0;
-    CrtCounters lastCounters;
+    CrtCounters lastCounters; unsigned long long lastCulled = 0;
 };
 State g;
 
-#define CRT_NUM_COUNTERS 14
+#define CRT_NUM_COUNTERS 15
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return (int)e_; } } while (0)
 #define RCCHK(x) do { int r_ = (x); if (r_ != CRT_OK) { return r_; } } while (0)
 
@@ -191,6 +191,28 @@ int alloc_frame_buffers(int w, int h)
     g.rays = rays; g.bounceQueue = queue; g.bounceCap = pixels;
     for (int i = 0; i < CRT_MAX_FRAMES_IN_FLIGHT; ++i) { if (g.slot[i].out) (void)hipFree(g.slot[i].out); g.slot[i].out = outs[i]; }
     g.width = w; g.height = h; g.readbackCount = 0;
+    return CRT_OK;
+}
+
+// Copies the pixel rows this rank owns (16-row bands dealt round-robin, crt_set_row_bands) from one frame-shaped buffer to
+// the same place in another: one strided 2-D copy (a band is contiguous, bands repeat every nRanks * bandRows rows) plus at
+// most one partial band at the bottom. Used for band-only read-backs and for the in-process multi-GPU gather.
+int copy_owned_rows_async(void* dstFrame, const void* srcFrame, size_t bytesPerPixel, hipMemcpyKind kind, hipStream_t stream)
+{
+    const size_t rowBytes = (size_t)g.width * bytesPerPixel;
+    if (g.nRanks == 1) return (int)hipMemcpyAsync(dstFrame, srcFrame, rowBytes * (size_t)g.height, kind, stream);
+    const size_t bandBytes = rowBytes * (size_t)g.bandRows, pitch = bandBytes * (size_t)g.nRanks;
+    const size_t first = (size_t)g.rank * bandBytes;                       // byte offset of this rank's first band
+    const int period = g.bandRows * g.nRanks, firstRow = g.rank * g.bandRows;
+    if (firstRow >= g.height) return CRT_OK;
+    const int fullBands = (g.height - firstRow) / period + (((g.height - firstRow) % period) >= g.bandRows ? 1 : 0);
+    char* d = static_cast<char*>(dstFrame) + first; const char* sp = static_cast<const char*>(srcFrame) + first;
+    if (fullBands > 0) HIPCHK(hipMemcpy2DAsync(d, pitch, sp, pitch, bandBytes, (size_t)fullBands, kind, stream));
+    const int tailRow = firstRow + fullBands * period;                     // a last, partial band?
+    if (tailRow < g.height) {
+        const size_t off = (size_t)fullBands * pitch, bytes = rowBytes * (size_t)(g.height - tailRow);
+        HIPCHK(hipMemcpyAsync(d + off, sp + off, bytes, kind, stream));
+    }
     return CRT_OK;
 }
 
@@ -385,7 +407,7 @@ int collect_set(EventSet& es)
         CrtCounters& o = g.lastCounters;
         o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
         o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
-        o.shadowRays = c[12]; o.shadowHits = c[13];
+        o.shadowRays = c[12]; o.shadowHits = c[13]; g.lastCulled = c[14];
     }
     es.pending = false;
     return CRT_OK;
@@ -1007,7 +1029,8 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
             HIPCHK(hipGetLastError());
             src = fs.packBuf;
         }
-        HIPCHK(hipMemcpyAsync(fs.hostBuf, src, bytes, hipMemcpyDeviceToHost, fs.stream));
+        // only the rows this rank renders travel (the host buffer keeps the full-frame layout)
+        RCCHK(copy_owned_rows_async(fs.hostBuf, src, bytes8 ? 4 : 16, hipMemcpyDeviceToHost, fs.stream));
         HIPCHK(hipEventRecord(fs.copied, fs.stream));
         fs.hostBytes = bytes; g.readbackRing[g.readbackCount++ % CRT_MAX_FRAMES_IN_FLIGHT] = slot;
     }
@@ -1060,7 +1083,7 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     CrtCounters& o = g.lastCounters;
     o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
     o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
-        o.shadowRays = c[12]; o.shadowHits = c[13];
+    o.shadowRays = c[12]; o.shadowHits = c[13]; g.lastCulled = c[14];
     return CRT_OK;
 }
 
@@ -1161,6 +1184,16 @@ int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
     const size_t n = maxWaves < g.stampWaves ? maxWaves : g.stampWaves;
     RCCHK(sync_all());
     HIPCHK(hipMemcpy(dst, g.stamps + 16, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt_get_culled_visits(uint64_t* out)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!out) return CRT_E_BAD_ARGUMENT;
+    int rc = collect_timing();
+    if (rc) return rc;
+    *out = g.lastCulled;
     return CRT_OK;
 }
 

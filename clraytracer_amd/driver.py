@@ -167,9 +167,10 @@ class Session:
             "num_textures": h.crth_num_textures(),
         }
 
-    def cpu_raycast(self, origins, dirs, nthreads=1):
+    def cpu_raycast(self, origins, dirs, nthreads=1, sse=False):
+        """CPU_RayCast over many rays; sse=True: upstream's SSE instruction mix (approximate rcpps), the timing flavour."""
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
         out = np.zeros(len(o), _lib.HITRECORD_DTYPE)
-        self.h.crth_cpu_raycast(o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data, int(nthreads))
+        (self.h.crth_cpu_raycast_sse if sse else self.h.crth_cpu_raycast)(o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data, int(nthreads))
         return out

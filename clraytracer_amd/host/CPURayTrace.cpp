@@ -106,11 +106,87 @@ inline RGB8 texel_at(long long idx)
     return g_TexturePixels[idx];
 }
 
+#if defined(__x86_64__)
+} // namespace
+#include <immintrin.h>
+namespace {
+// The reference's own instruction mix (CPURayTrace.cpp:42-128): one ray in two __m128 registers, _mm_dp_ps dot products,
+// the 12-bit _mm_rcp_ps estimates for 1/direction and for Moeller-Trumbore's 1/a. This flavour exists for TIMING
+// (bench.py's cpu_baseline, tools/cpu_baseline.py): `rcpps` is implementation-defined (Intel and AMD return different
+// bits), so its hit records can differ from the IEEE flavour above in the last places of t,u,v and -- rarely -- in which
+// triangle wins; tests only require the two to agree on >= 99.9 % of the rays.
+#define CRT_SSE41 __attribute__((target("sse4.1")))
+CRT_SSE41 inline __m128 load3z(const float* p) { return _mm_set_ps(0.0f, p[2], p[1], p[0]); }
+CRT_SSE41 inline __m128 cross_ps(__m128 a, __m128 b)
+{
+    const __m128 a_yzx = _mm_shuffle_ps(a, a, _MM_SHUFFLE(3, 0, 2, 1)), b_yzx = _mm_shuffle_ps(b, b, _MM_SHUFFLE(3, 0, 2, 1));
+    const __m128 c = _mm_sub_ps(_mm_mul_ps(a, b_yzx), _mm_mul_ps(a_yzx, b));
+    return _mm_shuffle_ps(c, c, _MM_SHUFFLE(3, 0, 2, 1));
+}
+CRT_SSE41 bool IntersectTriangleSSE(__m128 o, __m128 d, const Tri* tri, Triout* out, int i)
+{
+    const __m128 v0 = load3z(tri->v0);
+    const __m128 edge1 = _mm_sub_ps(load3z(tri->v1), v0), edge2 = _mm_sub_ps(load3z(tri->v2), v0);
+    const __m128 h = cross_ps(d, edge2);
+    const __m128 f = _mm_rcp_ps(_mm_dp_ps(edge1, h, 0x7f));
+    const __m128 s = _mm_sub_ps(o, v0);
+    const float u = _mm_cvtss_f32(_mm_mul_ps(f, _mm_dp_ps(s, h, 0x7f)));
+    const __m128 q = cross_ps(s, edge1);
+    const float v = _mm_cvtss_f32(_mm_mul_ps(f, _mm_dp_ps(d, q, 0x7f)));
+    const float t = _mm_cvtss_f32(_mm_mul_ps(f, _mm_dp_ps(edge2, q, 0x7f)));
+    const int passed = (((t > 0.0f) ^ (t < out->t)) + (u < 0.0f) + (u > 1.0f) + (v < 0.0f) + (u + v > 1.0f)) == 0;
+    const int notPassed = 1 - passed;
+    out->u = u * (float)passed + ((float)notPassed * out->u);
+    out->v = v * (float)passed + ((float)notPassed * out->v);
+    out->t = t * (float)passed + ((float)notPassed * out->t);
+    out->triIndex = (uint)i * (uint)passed + ((uint)notPassed * out->triIndex);
+    return passed != 0;
+}
+CRT_SSE41 inline float hmax3(__m128 v) { const __m128 m = _mm_max_ps(_mm_shuffle_ps(v, v, _MM_SHUFFLE(0, 0, 0, 0)), _mm_shuffle_ps(v, v, _MM_SHUFFLE(1, 1, 1, 1))); return _mm_cvtss_f32(_mm_max_ps(m, _mm_shuffle_ps(v, v, _MM_SHUFFLE(2, 2, 2, 2)))); }
+CRT_SSE41 inline float hmin3(__m128 v) { const __m128 m = _mm_min_ps(_mm_shuffle_ps(v, v, _MM_SHUFFLE(0, 0, 0, 0)), _mm_shuffle_ps(v, v, _MM_SHUFFLE(1, 1, 1, 1))); return _mm_cvtss_f32(_mm_min_ps(m, _mm_shuffle_ps(v, v, _MM_SHUFFLE(2, 2, 2, 2)))); }
+CRT_SSE41 inline float IntersectAABBSSE(__m128 o, __m128 inv, const float* bmin, const float* bmax, float minSoFar)
+{
+    const __m128 t0 = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(bmin), o), inv), t1 = _mm_mul_ps(_mm_sub_ps(_mm_loadu_ps(bmax), o), inv);
+    const float tnear = hmax3(_mm_min_ps(t0, t1)), tfar = hmin3(_mm_max_ps(t0, t1));
+    return (tnear < tfar && tnear > 0.0f && tnear < minSoFar) ? tnear : RayacastMissDistance;
+}
+CRT_SSE41 bool IntersectBVHSSE(V3 o3, V3 d3, const BVHNode* nodes, uint rootNode, const Tri* tris, Triout* out)
+{
+    const __m128 o = _mm_set_ps(1.0f, o3.z, o3.y, o3.x), d = _mm_set_ps(0.0f, d3.z, d3.y, d3.x);
+    uint stack[32] = { rootNode };
+    int sp = 1, protection = 0;
+    const __m128 inv = _mm_rcp_ps(d);
+    bool intersection = false;
+    while (sp > 0 && protection++ < 250) {
+        const BVHNode* node = nodes + stack[--sp & 31];
+        for (;;) {
+            if (node->triCount > 0) {
+                for (int i = (int)node->leftFirst, end = i + (int)node->triCount; i < end; ++i)
+                    intersection |= IntersectTriangleSSE(o, d, tris + i, out, i);
+                break;
+            }
+            uint l = node->leftFirst, r = l + 1;
+            float d1 = IntersectAABBSSE(o, inv, nodes[l].aabbMin, nodes[l].aabbMax, out->t);
+            float d2 = IntersectAABBSSE(o, inv, nodes[r].aabbMin, nodes[r].aabbMax, out->t);
+            if (d1 > d2) { float tf = d1; d1 = d2; d2 = tf; uint tu = l; l = r; r = tu; }
+            if (d1 == RayacastMissDistance) break;
+            node = nodes + l;
+            if (d2 != RayacastMissDistance) { stack[sp & 31] = r; ++sp; }
+        }
+    }
+    return intersection;
+}
+#define CRT_HAVE_SSE_FLAVOUR 1
+#endif
+
 } // namespace
 
 void CPU_RayTraceInitialize() {}
 
-HitRecord CPU_RayCast(RaySSE ray) // CPURayTrace.cpp:186-249
+namespace {
+typedef bool (*BvhFn)(V3, V3, const BVHNode*, uint, const Tri*, Triout*);
+template <BvhFn INTERSECT>
+HitRecord ray_cast(RaySSE ray) // CPURayTrace.cpp:186-249
 {
     HitRecord record;
     std::memset(&record, 0, sizeof record);
@@ -131,7 +207,7 @@ HitRecord CPU_RayCast(RaySSE ray) // CPURayTrace.cpp:186-249
             o3[c] = (m[0][c] * ov[0] + m[1][c] * ov[1]) + (m[2][c] * ov[2] + m[3][c] * ov[3]);
             d3[c] = (m[0][c] * dv[0] + m[1][c] * dv[1]) + (m[2][c] * dv[2] + m[3][c] * dv[3]);
         }
-        if (IntersectBVH(load3(o3), load3(d3), g_BVHNodes, g_BVHIndices[instance.meshIndex], g_Triangles, &triout)) {
+        if (INTERSECT(load3(o3), load3(d3), g_BVHNodes, g_BVHIndices[instance.meshIndex], g_Triangles, &triout)) {
             hitOut = triout; hitInstanceIndex = i; bestDistance = triout.t; bestIndex = instance.meshIndex;
         }
     }
@@ -175,4 +251,16 @@ HitRecord CPU_RayCast(RaySSE ray) // CPURayTrace.cpp:186-249
     record.distance = bestDistance;
     record.index = bestIndex;
     return record;
+}
+} // namespace
+
+HitRecord CPU_RayCast(RaySSE ray) { return ray_cast<IntersectBVH>(ray); }
+
+// The reference's SSE instruction mix (approximate _mm_rcp_ps); falls back to CPU_RayCast where SSE4.1 is not available.
+HitRecord CPU_RayCastSSE(RaySSE ray)
+{
+#ifdef CRT_HAVE_SSE_FLAVOUR
+    if (__builtin_cpu_supports("sse4.1")) return ray_cast<IntersectBVHSSE>(ray);
+#endif
+    return ray_cast<IntersectBVH>(ray);
 }

@@ -9,3 +9,6 @@ constexpr float RayacastMissDistance = 1e30f;
 
 void CPU_RayTraceInitialize();
 HitRecord CPU_RayCast(RaySSE ray);
+// Timing flavour with upstream's instruction mix (_mm_dp_ps, 12-bit _mm_rcp_ps; CPURayTrace.cpp:42-128). `rcpps` is
+// implementation-defined, so results may differ from CPU_RayCast in the last places; not used for parity.
+HitRecord CPU_RayCastSSE(RaySSE ray);

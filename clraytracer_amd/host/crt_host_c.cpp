@@ -103,15 +103,19 @@ unsigned crth_render(float sunAngle)
 const float* crth_map_output(void) { return hostOnly ? nullptr : Renderer::MapOutput(); }
 float crth_last_frame_ms(void) { return hostOnly ? -1.0f : Renderer::LastFrameMs(); }
 
-void crth_cpu_raycast(const float* origins, const float* dirs, int n, CrtHitRecord* out, int nthreads)
+static void cpu_raycast_many(HitRecord (*cast)(RaySSE), const float* origins, const float* dirs, int n, CrtHitRecord* out, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
+    // blocks of 4096 rays dealt round-robin: neighbouring rays stay on one thread (cache-friendly), load stays balanced
     auto work = [&](int t) {
-        for (int k = t; k < n; k += nthreads) {
-            RaySSE r;
-            r.origin[0] = origins[3 * k]; r.origin[1] = origins[3 * k + 1]; r.origin[2] = origins[3 * k + 2]; r.origin[3] = 1.0f;
-            r.direction[0] = dirs[3 * k]; r.direction[1] = dirs[3 * k + 1]; r.direction[2] = dirs[3 * k + 2]; r.direction[3] = 0.0f;
-            out[k] = CPU_RayCast(r);
+        for (int base = t * 4096; base < n; base += nthreads * 4096) {
+            const int end = base + 4096 < n ? base + 4096 : n;
+            for (int k = base; k < end; ++k) {
+                RaySSE r;
+                r.origin[0] = origins[3 * k]; r.origin[1] = origins[3 * k + 1]; r.origin[2] = origins[3 * k + 2]; r.origin[3] = 1.0f;
+                r.direction[0] = dirs[3 * k]; r.direction[1] = dirs[3 * k + 1]; r.direction[2] = dirs[3 * k + 2]; r.direction[3] = 0.0f;
+                out[k] = cast(r);
+            }
         }
     };
     if (nthreads == 1) { work(0); return; }
@@ -119,6 +123,8 @@ void crth_cpu_raycast(const float* origins, const float* dirs, int n, CrtHitReco
     for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
     for (auto& th : pool) th.join();
 }
+void crth_cpu_raycast(const float* origins, const float* dirs, int n, CrtHitRecord* out, int nthreads) { cpu_raycast_many(CPU_RayCast, origins, dirs, n, out, nthreads); }
+void crth_cpu_raycast_sse(const float* origins, const float* dirs, int n, CrtHitRecord* out, int nthreads) { cpu_raycast_many(CPU_RayCastSSE, origins, dirs, n, out, nthreads); }
 
 const CrtTri* crth_triangles(void) { return g_Triangles; }
 size_t crth_num_triangles(void) { return ResourceManager::NumTriangles(); }

@@ -146,6 +146,10 @@ typedef struct CrtFrameStats {
 } CrtFrameStats;
 int crt_frame_time_stats(CrtFrameStats* out, int reset);
 int crt_get_counters(CrtCounters* out);
+/* Of the last counted launch's `traversals` (= pops = root visits, one per ray and instance as upstream spends them,
+ * kernel_main.cl:198-217), how many the conservative instance cull answered without fetching anything: the device's
+ * real child-pair fetches are innerVisits - this. (Measurement aid for bench.py's gather-rate figure.) */
+int crt_get_culled_visits(uint64_t* out);
 /* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 8 x uint64 {start, end (s_memrealtime, 100 MHz),
  * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer / enter-instance / descent loops,
  * leaf trips << 32 | lane-level node visits}. Pass dst = NULL to query the wave count. */

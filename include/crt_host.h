@@ -62,6 +62,8 @@ float crth_last_frame_ms(void);
 
 /* CPU_RayCast (CPURayTrace.cpp:186) over n rays (xyz triples). */
 void crth_cpu_raycast(const float* origins, const float* dirs, int n, CrtHitRecord* out, int nthreads);
+/* CPU_RayCastSSE: the same with upstream's SSE instruction mix (_mm_dp_ps, approximate _mm_rcp_ps) -- the timing flavour. */
+void crth_cpu_raycast_sse(const float* origins, const float* dirs, int n, CrtHitRecord* out, int nthreads);
 
 /* read-only views of the host arenas (ResourceManager.cpp:49-55, Renderer.cpp:45-50) */
 const CrtTri* crth_triangles(void);         size_t crth_num_triangles(void);

@@ -2,7 +2,7 @@
 # Vector-memory-path PMC passes (TCP / TD / SQ), one small group per run, each under its own timeout
 # (a TA_* group hung rocprofv3 on this pool once: TA counters are deliberately not collected).
 # Usage: tools/run_pmc_mem.sh <tag>
-tag=${1:-r01}
+tag=${1:-r02}
 export TMPDIR=/tmp
 S="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 i=0

@@ -3,7 +3,7 @@
 # command plus separate PMC passes (one counter group per run; never combined with other tracing).
 # Usage: tools/run_profiles.sh <tag>      -> gpurun_out/prof_<tag>_*/ ; summarise with tools/profile_summary.py
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 export TMPDIR=/tmp
 out=gpurun_out
 B="python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline"
