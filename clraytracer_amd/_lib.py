@@ -58,6 +58,9 @@ _sz = C.c_size_t
 # name -> (restype, argtypes); kept in sync with include/crt_api.h (tests/test_abi.py checks it)
 HIP_API = {
     "crt_init": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "crt_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]),
+    "crt_init_gpus": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "crt_num_devices": (C.c_int, []),
     "crt_shutdown": (C.c_int, []),
     "crt_resize": (C.c_int, [C.c_int, C.c_int]),
     "crt_set_row_bands": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -95,6 +98,7 @@ HIP_API = {
 
 HOST_API = {
     "crth_initialize": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "crth_initialize_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]),
     "crth_initialize_host_only": (C.c_int, [C.c_int, C.c_int]),
     "crth_terminate": (None, []),
     "crth_last_error": (C.c_int, []),

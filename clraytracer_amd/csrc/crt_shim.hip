@@ -16,6 +16,10 @@
 #include <vector>
 #include <algorithm>
 #include <utility>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 
 // ------------------------------------------------------------------------------------------------
 // host state
@@ -23,6 +27,7 @@
 namespace {
 
 #define CRT_MAX_FRAMES_IN_FLIGHT 4
+#define CRT_MAX_DEVICES 16
 
 struct EventSet {
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -48,6 +53,9 @@ struct FrameSlot {
     CrtTlasNode* tlas = nullptr; uint32_t* alwaysList = nullptr; uint32_t tlasNodes = 0, numAlways = 0;
     unsigned long long instVersion = 0;        // 0 = never filled (the master starts at 1)
     char* staging = nullptr; hipEvent_t staged = nullptr;   // pinned staging block and "its copies have been issued and done" event
+    // in-process multi-GPU (crt_init_devices): a secondary device records `partDone` behind the copy of its bands into the
+    // primary's frame; the primary records `slotDone` behind everything a frame queues on this slot (incl. a read-back)
+    hipEvent_t partDone = nullptr, slotDone = nullptr;
 };
 
 struct State {
@@ -93,8 +101,14 @@ struct State {
     float ms[4] = { 0, 0, 0, 0 }; unsigned long long msSeq = 0, frameSeq = 0;   // timing of the newest frame read back so far
     hipEvent_t statStart = nullptr; bool statStartArmed = true, statStartValid = false; unsigned long long statStartSeq = 0; double statExtent = 0;
     CrtCounters lastCounters; unsigned long long lastCulled = 0;
+    // in-process multi-GPU: this device renders band `rank` of `nRanks`; `primary` (rank 0) owns the frame that is read
+    State* primary = nullptr; State* group[CRT_MAX_DEVICES] = { nullptr }; int groupSize = 1;
 };
-State g;
+// One State per device (crt_init: one; crt_init_devices: one per GPU). Every function below works on "the current
+// device's state" through `g`; the dispatch layer at the end of the file selects it (and the HIP device) per call, on the
+// calling thread or on a per-device worker thread.
+thread_local State* G = nullptr;
+#define g (*G)
 
 #define CRT_NUM_COUNTERS 15
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return (int)e_; } } while (0)
@@ -197,10 +211,10 @@ int alloc_frame_buffers(int w, int h)
 // Copies the pixel rows this rank owns (16-row bands dealt round-robin, crt_set_row_bands) from one frame-shaped buffer to
 // the same place in another: one strided 2-D copy (a band is contiguous, bands repeat every nRanks * bandRows rows) plus at
 // most one partial band at the bottom. Used for band-only read-backs and for the in-process multi-GPU gather.
-int copy_owned_rows_async(void* dstFrame, const void* srcFrame, size_t bytesPerPixel, hipMemcpyKind kind, hipStream_t stream)
+int copy_owned_rows_async(void* dstFrame, const void* srcFrame, size_t bytesPerPixel, hipMemcpyKind kind, hipStream_t stream, bool allRows = false)
 {
     const size_t rowBytes = (size_t)g.width * bytesPerPixel;
-    if (g.nRanks == 1) return (int)hipMemcpyAsync(dstFrame, srcFrame, rowBytes * (size_t)g.height, kind, stream);
+    if (g.nRanks == 1 || allRows) return (int)hipMemcpyAsync(dstFrame, srcFrame, rowBytes * (size_t)g.height, kind, stream);
     const size_t bandBytes = rowBytes * (size_t)g.bandRows, pitch = bandBytes * (size_t)g.nRanks;
     const size_t first = (size_t)g.rank * bandBytes;                       // byte offset of this rank's first band
     const int period = g.bandRows * g.nRanks, firstRow = g.rank * g.bandRows;
@@ -428,22 +442,13 @@ int collect_timing()
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
-extern "C" {
+namespace {
+// ---- per-device implementation of the C-ABI entry points (current state = g) ----
 
-const char* crt_error_string(int code)
-{
-    switch (code) {
-    case CRT_OK: return "ok";
-    case CRT_E_NOT_INITIALIZED: return "crt: not initialized (crt_init failed or was not called)";
-    case CRT_E_BAD_ARGUMENT: return "crt: bad argument or invalid scene data";
-    case CRT_E_OUT_OF_RANGE: return "crt: upload exceeds a fixed device pool";
-    case CRT_E_NO_DEVICE: return "crt: no usable HIP device";
-    case CRT_E_UNSUPPORTED: return "crt: unsupported";
-    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "crt: unknown error";
-    }
-}
 
-const char* crt_device_name(void) { return g.deviceName; }
+const char* crt1_device_name(void) { return g.deviceName; }
+
+int crt1_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes);
 
 static int init_impl(int device, int width, int height)
 {
@@ -468,6 +473,8 @@ static int init_impl(int device, int width, int height)
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&fs.staging), kStageBytes, hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&fs.staged, hipEventDisableTiming));
         HIPCHK(hipEventRecord(fs.staged, fs.stream));
+        HIPCHK(hipEventCreateWithFlags(&fs.partDone, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&fs.slotDone, hipEventDisableTiming));
         fs.instVersion = 0;
     }
     HIPCHK(hipEventCreate(&g.statStart));
@@ -519,10 +526,10 @@ static int init_impl(int device, int width, int height)
     g.initialized = true;
     // default white / black texels (ResourceManager.cpp:168-177)
     const unsigned char def[6] = { 0xFF, 0xFF, 0xFF, 0, 0, 0 };
-    return crt_upload_texels(def, 0, 6);
+    return crt1_upload_texels(def, 0, 6);
 }
 
-// frees everything State holds (also after a crt_init that failed half way) and resets it
+// frees everything State holds (also after an init that failed half way) and resets it
 static void release_all()
 {
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
@@ -534,6 +541,8 @@ static void release_all()
         for (void* p : q) if (p) (void)hipFree(p);
         if (fs.staging) (void)hipHostFree(fs.staging);
         if (fs.staged) (void)hipEventDestroy(fs.staged);
+        if (fs.partDone) (void)hipEventDestroy(fs.partDone);
+        if (fs.slotDone) (void)hipEventDestroy(fs.slotDone);
         if (fs.hostBuf) (void)hipHostFree(fs.hostBuf);
         if (fs.copied) (void)hipEventDestroy(fs.copied);
     }
@@ -543,25 +552,10 @@ static void release_all()
         for (EventSet& es : fs.es) for (int i = 0; i < 4; ++i) if (es.ev[i]) (void)hipEventDestroy(es.ev[i]);
         if (fs.stream) (void)hipStreamDestroy(fs.stream);
     }
-    g = State();
+    { State* me = G; *me = State(); }
 }
 
-int crt_init(int device, int width, int height)
-{
-    if (g.initialized) return CRT_E_BAD_ARGUMENT;
-    const int rc = init_impl(device, width, height);
-    if (rc != CRT_OK) release_all();           // nothing stays allocated after a failed init
-    return rc;
-}
-
-int crt_shutdown(void)
-{
-    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
-    release_all();
-    return CRT_OK;
-}
-
-int crt_resize(int width, int height)
+int crt1_resize(int width, int height)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (width < 16 || height < 16) return CRT_OK; // Renderer.cpp:200
@@ -569,7 +563,7 @@ int crt_resize(int width, int height)
     return alloc_frame_buffers(width, height);
 }
 
-int crt_set_row_bands(int bandRows, int rank, int nRanks)
+int crt1_set_row_bands(int bandRows, int rank, int nRanks)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
@@ -578,13 +572,8 @@ int crt_set_row_bands(int bandRows, int rank, int nRanks)
     return CRT_OK;
 }
 
-int crt_row_owner(int row, int bandRows, int nRanks)
-{
-    if (row < 0 || bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1) return CRT_E_BAD_ARGUMENT;
-    return (row / bandRows) % nRanks;
-}
 
-int crt_owned_rows(void)
+int crt1_owned_rows(void)
 {
     if (!g.initialized) return 0;
     int rows = 0;
@@ -593,7 +582,7 @@ int crt_owned_rows(void)
     return rows;
 }
 
-int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes)
+int crt1_upload_triangles(const void* tris, size_t byteOffset, size_t bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (bytes == 0) return CRT_OK;
@@ -609,7 +598,7 @@ int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes)
     return CRT_OK;
 }
 
-int crt_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes)
+int crt1_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (bytes == 0) return CRT_OK;
@@ -622,7 +611,7 @@ int crt_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes)
     return rebuild_bvh_layout();
 }
 
-int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count)
+int crt1_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (count == 0) return CRT_OK;
@@ -635,7 +624,7 @@ int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count)
     return rebuild_bvh_layout();
 }
 
-int crt_upload_materials(const void* materials, size_t first, size_t count)
+int crt1_upload_materials(const void* materials, size_t first, size_t count)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (count == 0) return CRT_OK;
@@ -647,7 +636,7 @@ int crt_upload_materials(const void* materials, size_t first, size_t count)
     return CRT_OK;
 }
 
-int crt_upload_texture_table(const void* textures, size_t count)
+int crt1_upload_texture_table(const void* textures, size_t count)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (count == 0) return CRT_OK;
@@ -659,7 +648,7 @@ int crt_upload_texture_table(const void* textures, size_t count)
     return CRT_OK;
 }
 
-int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes)
+int crt1_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (bytes == 0) return CRT_OK;
@@ -679,7 +668,7 @@ int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes)
     return CRT_OK;
 }
 
-int crt_upload_instances(const void* instances, size_t first, size_t count)
+int crt1_upload_instances(const void* instances, size_t first, size_t count)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (count == 0) return CRT_OK;
@@ -696,7 +685,7 @@ int crt_upload_instances(const void* instances, size_t first, size_t count)
 }
 
 // BuildBVH on the device (crt_bvh_build.h): same triangle order, node numbering and bounds as the host builder.
-int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes, size_t firstNode, size_t firstMesh, uint32_t* nodesUsedOut)
+int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes, size_t firstNode, size_t firstMesh, uint32_t* nodesUsedOut)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!meshTriCounts || numMeshes < 1) return CRT_E_BAD_ARGUMENT;
@@ -813,9 +802,9 @@ int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes,
     return rebuild_bvh_layout();
 }
 
-// Read back the reference-layout pools (after crt_build_bvh: the reordered triangles with their centroids, the nodes,
+// Read back the reference-layout pools (after crt1_build_bvh: the reordered triangles with their centroids, the nodes,
 // the roots), e.g. to keep host arenas in step with the device.
-int crt_download_triangles(void* dst, size_t byteOffset, size_t bytes)
+int crt1_download_triangles(void* dst, size_t byteOffset, size_t bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (bytes == 0) return CRT_OK;
@@ -826,7 +815,7 @@ int crt_download_triangles(void* dst, size_t byteOffset, size_t bytes)
     return CRT_OK;
 }
 
-int crt_download_bvh_nodes(void* dst, size_t byteOffset, size_t bytes)
+int crt1_download_bvh_nodes(void* dst, size_t byteOffset, size_t bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (bytes == 0) return CRT_OK;
@@ -837,7 +826,7 @@ int crt_download_bvh_nodes(void* dst, size_t byteOffset, size_t bytes)
     return CRT_OK;
 }
 
-int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count)
+int crt1_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (count == 0) return CRT_OK;
@@ -851,7 +840,7 @@ int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count)
 // Feedback launch lists for the megakernel (lane_pixel / crt_order_kernel). Buffers follow the frame geometry; a
 // change of geometry resets to the identity order. The previous frame's per-tile costs are turned into this frame's
 // lists (and the costs zeroed) by a sort that is queued right AFTER the previous frame's last kernel and its end
-// event (sort_for_next_frame), so it runs while the host is between two crt_render calls and is off the frame's
+// event (sort_for_next_frame), so it runs while the host is between two crt1_render calls and is off the frame's
 // critical path (it used to open every frame: 10 us + a launch gap of a 0.5 ms synchronous frame).
 static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool pipelined)
 {
@@ -936,7 +925,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
     return CRT_OK;
 }
 
-int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags)
+int crt1_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!args || !invView || !invProj) return CRT_E_BAD_ARGUMENT;
@@ -991,6 +980,15 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     }
     rc = launch_trace(S, F, flags, grid, fs);
     if (rc) return rc;
+    // in-process multi-GPU, primary device: the frame is complete when every secondary's bands have arrived -- its last
+    // event is recorded behind waits for their partDone events (recorded before this call: the dispatcher submits the
+    // secondaries first)
+    const bool isPrimary = g.groupSize > 1 && g.primary == G, isSecondary = g.groupSize > 1 && g.primary != G;
+    auto wait_for_parts = [&]() -> int {
+        for (int d = 1; d < g.groupSize; ++d) HIPCHK(hipStreamWaitEvent(fs.stream, g.group[d]->slot[slot].partDone, 0));
+        return CRT_OK;
+    };
+    if (isPrimary && !es.evPost) RCCHK(wait_for_parts());
     HIPCHK(hipEventRecord(es.ev[2], fs.stream));
     if (es.evPost) {
         // upstream: Trace write_imagef's into an RGBA8 texture, PostProcess read_imagef's it back and write_imagef's again
@@ -999,7 +997,16 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
         if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
         if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
         HIPCHK(hipGetLastError());
+        if (isPrimary) RCCHK(wait_for_parts());
         HIPCHK(hipEventRecord(es.ev[3], fs.stream));
+    }
+    if (isSecondary) {
+        // gather: this device's bands go into the primary's frame of the same slot (peer copy over xGMI), once the primary
+        // is done with whatever the slot's previous frame still had queued (its read-back)
+        FrameSlot& pfs = g.primary->slot[slot];
+        HIPCHK(hipStreamWaitEvent(fs.stream, pfs.slotDone, 0));
+        RCCHK(copy_owned_rows_async(pfs.out, fs.out, 16, hipMemcpyDeviceToDevice, fs.stream));
+        HIPCHK(hipEventRecord(fs.partDone, fs.stream));
     }
     g.cur = slot;
     es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
@@ -1030,23 +1037,24 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
             src = fs.packBuf;
         }
         // only the rows this rank renders travel (the host buffer keeps the full-frame layout)
-        RCCHK(copy_owned_rows_async(fs.hostBuf, src, bytes8 ? 4 : 16, hipMemcpyDeviceToHost, fs.stream));
+        RCCHK(copy_owned_rows_async(fs.hostBuf, src, bytes8 ? 4 : 16, hipMemcpyDeviceToHost, fs.stream, isPrimary));
         HIPCHK(hipEventRecord(fs.copied, fs.stream));
         fs.hostBytes = bytes; g.readbackRing[g.readbackCount++ % CRT_MAX_FRAMES_IN_FLIGHT] = slot;
     }
+    if (isPrimary) HIPCHK(hipEventRecord(fs.slotDone, fs.stream));
     // the reference's clFinish (Renderer.cpp:367): wait for the frame's end event -- the sort for the next frame that is
     // queued behind it needs no waiting for
     if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipEventSynchronize(es.evPost ? es.ev[3] : es.ev[2]));
     return CRT_OK;
 }
 
-int crt_sync(void)
+int crt1_sync(void)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     return sync_all();
 }
 
-int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out)
+int crt1_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (n <= 0) return CRT_OK;
@@ -1087,7 +1095,7 @@ int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numI
     return CRT_OK;
 }
 
-int crt_read_output(float* dst, size_t floats)
+int crt1_read_output(float* dst, size_t floats)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || floats != (size_t)g.width * (size_t)g.height * 4) return CRT_E_BAD_ARGUMENT;
@@ -1096,7 +1104,7 @@ int crt_read_output(float* dst, size_t floats)
     return CRT_OK;
 }
 
-int crt_read_output_rows(float* dst, int row0, int rows)
+int crt1_read_output_rows(float* dst, int row0, int rows)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || row0 < 0 || rows < 0 || row0 + rows > g.height) return CRT_E_BAD_ARGUMENT;
@@ -1105,7 +1113,7 @@ int crt_read_output_rows(float* dst, int row0, int rows)
     return CRT_OK;
 }
 
-int crt_read_output_rgba8(uint8_t* dst, size_t bytes)
+int crt1_read_output_rgba8(uint8_t* dst, size_t bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     const size_t pixels = (size_t)g.width * (size_t)g.height;
@@ -1124,7 +1132,7 @@ int crt_read_output_rgba8(uint8_t* dst, size_t bytes)
     return CRT_OK;
 }
 
-int crt_map_host_frame_back(int framesBack, const void** ptr, size_t* bytes)
+int crt1_map_host_frame_back(int framesBack, const void** ptr, size_t* bytes)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     // a pipelined frame's copy lives in its slot until the slot is reused: the last nSlots READBACK frames are reachable
@@ -1139,9 +1147,9 @@ int crt_map_host_frame_back(int framesBack, const void** ptr, size_t* bytes)
     return CRT_OK;
 }
 
-int crt_map_host_frame(const void** ptr, size_t* bytes) { return crt_map_host_frame_back(0, ptr, bytes); }
+int crt1_map_host_frame(const void** ptr, size_t* bytes) { return crt1_map_host_frame_back(0, ptr, bytes); }
 
-int crt_read_rays(float* dst, size_t floats)
+int crt1_read_rays(float* dst, size_t floats)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || floats != (size_t)g.width * (size_t)g.height * 3) return CRT_E_BAD_ARGUMENT;
@@ -1150,16 +1158,16 @@ int crt_read_rays(float* dst, size_t floats)
     return CRT_OK;
 }
 
-void* crt_output_device_ptr(void) { return g.initialized ? (void*)g.slot[g.cur].out : nullptr; }
+void* crt1_output_device_ptr(void) { return g.initialized ? (void*)g.slot[g.cur].out : nullptr; }
 
-float crt_last_kernel_ms(int which)
+float crt1_last_kernel_ms(int which)
 {
     if (!g.initialized || which < 0 || which > 3) return -1.0f;
     if (collect_timing() != CRT_OK) return -1.0f;
     return g.ms[which];
 }
 
-int crt_frame_time_stats(CrtFrameStats* out, int reset)
+int crt1_frame_time_stats(CrtFrameStats* out, int reset)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     RCCHK(collect_timing());
@@ -1175,7 +1183,7 @@ int crt_frame_time_stats(CrtFrameStats* out, int reset)
     return CRT_OK;
 }
 
-int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
+int crt1_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!numWaves) return CRT_E_BAD_ARGUMENT;
@@ -1187,7 +1195,7 @@ int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
     return CRT_OK;
 }
 
-int crt_get_culled_visits(uint64_t* out)
+int crt1_get_culled_visits(uint64_t* out)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!out) return CRT_E_BAD_ARGUMENT;
@@ -1197,7 +1205,7 @@ int crt_get_culled_visits(uint64_t* out)
     return CRT_OK;
 }
 
-int crt_get_counters(CrtCounters* out)
+int crt1_get_counters(CrtCounters* out)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!out) return CRT_E_BAD_ARGUMENT;
@@ -1207,4 +1215,245 @@ int crt_get_counters(CrtCounters* out)
     return CRT_OK;
 }
 
+} // namespace
+
+extern "C" {
+
+const char* crt_error_string(int code)
+{
+    switch (code) {
+    case CRT_OK: return "ok";
+    case CRT_E_NOT_INITIALIZED: return "crt: not initialized (crt_init failed or was not called)";
+    case CRT_E_BAD_ARGUMENT: return "crt: bad argument or invalid scene data";
+    case CRT_E_OUT_OF_RANGE: return "crt: upload exceeds a fixed device pool";
+    case CRT_E_NO_DEVICE: return "crt: no usable HIP device";
+    case CRT_E_UNSUPPORTED: return "crt: unsupported";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "crt: unknown error";
+    }
+}
+
+int crt_row_owner(int row, int bandRows, int nRanks)
+{
+    if (row < 0 || bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1) return CRT_E_BAD_ARGUMENT;
+    return (row / bandRows) % nRanks;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Dispatch: one device (crt_init) or several in one process (crt_init_devices / crt_init_gpus)
+//
+// The reference drives ONE OpenCL device from one thread (Renderer.cpp:134 asks clGetDeviceIDs for a single GPU). With
+// several devices the same C-ABI is kept: the scene is replicated by every upload, the frame is cut into 16-row bands
+// dealt round-robin to the devices (device d = rank d of n), every device traces its bands with its own streams and frame
+// slots, copies them into the primary device's frame (hipMemcpy2DAsync peer copies, one strided copy per device and frame,
+// over xGMI) and the primary's end-of-frame event waits for those copies -- so crt_render keeps upstream's
+// Render() + clFinish meaning, crt_read_output / crt_map_host_frame / crt_output_device_ptr return the WHOLE frame, and
+// frames in flight work as before. No collective and no host staging in the data path. Each secondary device has a
+// host worker thread that submits its share of a frame, so the per-frame submission cost does not grow with the number of
+// devices; the calling thread submits the primary's share last (its stream must wait on events the others have recorded).
+// ------------------------------------------------------------------------------------------------
+struct Worker {
+    std::thread th; std::mutex m; std::condition_variable cv;
+    std::function<int()> job; bool hasJob = false, quit = false, done = true; int result = 0;
+    State* st = nullptr; int device = 0;
+    void start(State* s, int dev)
+    {
+        st = s; device = dev;
+        th = std::thread([this] {
+            (void)hipSetDevice(device);
+            G = st;
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this] { return hasJob || quit; });
+                if (quit) return;
+                std::function<int()> f = std::move(job); hasJob = false;
+                lk.unlock();
+                const int r = f();
+                lk.lock();
+                result = r; done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<int()> f) { std::lock_guard<std::mutex> lk(m); job = std::move(f); hasJob = true; done = false; cv.notify_all(); }
+    int wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return done; }); return result; }
+    void stop() { { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); } if (th.joinable()) th.join(); }
+};
+
+struct Group {
+    int n = 0;                                  // 0: no session; 1: crt_init; >1: crt_init_devices
+    State* dev[CRT_MAX_DEVICES] = { nullptr };
+    int hipDevice[CRT_MAX_DEVICES] = { 0 };
+    Worker* worker[CRT_MAX_DEVICES] = { nullptr };
+} M;
+
+// selects device d of the session for the calling thread; the primary is re-selected when the scope ends
+struct Use {
+    explicit Use(int d) { select(d); }
+    ~Use() { if (M.n > 1) select(0); }
+    static void select(int d) { if (M.n > d && M.dev[d]) { if (M.n > 1) (void)hipSetDevice(M.hipDevice[d]); G = M.dev[d]; } else G = nullptr; }
+};
+#define NEED_SESSION() do { if (M.n == 0) return CRT_E_NOT_INITIALIZED; } while (0)
+// run `expr` on every device of the session (scene uploads, resize, ...); first error wins
+#define ON_ALL(expr) do { NEED_SESSION(); int rc_ = CRT_OK; for (int d_ = 0; d_ < M.n; ++d_) { Use u_(d_); const int r_ = (expr); if (r_ != CRT_OK && rc_ == CRT_OK) rc_ = r_; } return rc_; } while (0)
+#define ON_PRIMARY(expr) do { NEED_SESSION(); Use u_(0); return (expr); } while (0)
+
+static void destroy_group()
+{
+    for (int d = 1; d < M.n; ++d) if (M.worker[d]) { M.worker[d]->stop(); delete M.worker[d]; M.worker[d] = nullptr; }
+    for (int d = 0; d < M.n; ++d) {
+        if (!M.dev[d]) continue;
+        if (M.n > 1) (void)hipSetDevice(M.hipDevice[d]);
+        G = M.dev[d];
+        release_all();
+        delete M.dev[d]; M.dev[d] = nullptr;
+    }
+    G = nullptr; M.n = 0;
+}
+
+int crt_init_devices(const int* devices, int numDevices, int width, int height)
+{
+    if (M.n != 0) return CRT_E_BAD_ARGUMENT;
+    if (!devices || numDevices < 1 || numDevices > CRT_MAX_DEVICES) return CRT_E_BAD_ARGUMENT;
+    int rc = CRT_OK;
+    M.n = numDevices;
+    for (int d = 0; d < numDevices && rc == CRT_OK; ++d) {
+        M.hipDevice[d] = devices[d];
+        M.dev[d] = new State();
+        G = M.dev[d];
+        rc = init_impl(devices[d], width, height);           // selects the HIP device
+        if (rc == CRT_OK && numDevices > 1) {
+            g.bandRows = 16; g.rank = d; g.nRanks = numDevices;
+            g.primary = M.dev[0]; g.groupSize = numDevices;
+            if (d > 0 && devices[d] != devices[0]) {
+                // peer copies into the primary's frame and cross-device event waits
+                int can = 0;
+                (void)hipDeviceCanAccessPeer(&can, devices[d], devices[0]);
+                if (can) { const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = (int)e; (void)hipGetLastError(); }
+            }
+        }
+    }
+    if (rc == CRT_OK && numDevices > 1) {
+        for (int d = 0; d < numDevices; ++d) for (int k = 0; k < numDevices; ++k) M.dev[d]->group[k] = M.dev[k];
+        for (int d = 1; d < numDevices; ++d) { M.worker[d] = new Worker(); M.worker[d]->start(M.dev[d], devices[d]); }
+    }
+    if (rc != CRT_OK) { destroy_group(); return rc; }
+    Use::select(0);
+    return CRT_OK;
+}
+
+int crt_init(int device, int width, int height) { return crt_init_devices(&device, 1, width, height); }
+
+int crt_init_gpus(int numGpus, int width, int height)
+{
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return CRT_E_NO_DEVICE;
+    if (numGpus < 1 || numGpus > have || numGpus > CRT_MAX_DEVICES) return CRT_E_BAD_ARGUMENT;
+    int ids[CRT_MAX_DEVICES];
+    for (int d = 0; d < numGpus; ++d) ids[d] = d;
+    return crt_init_devices(ids, numGpus, width, height);
+}
+
+int crt_num_devices(void) { return M.n; }
+
+int crt_shutdown(void)
+{
+    NEED_SESSION();
+    destroy_group();
+    return CRT_OK;
+}
+
+const char* crt_device_name(void) { if (M.n == 0) return ""; Use u(0); return crt1_device_name(); }
+
+int crt_resize(int width, int height) { ON_ALL(crt1_resize(width, height)); }
+int crt_set_row_bands(int bandRows, int rank, int nRanks)
+{
+    NEED_SESSION();
+    if (M.n > 1) return CRT_E_UNSUPPORTED;                  // the bands belong to the devices of this session
+    ON_PRIMARY(crt1_set_row_bands(bandRows, rank, nRanks));
+}
+int crt_owned_rows(void) { if (M.n == 0) return 0; Use u(0); return M.n > 1 ? g.height : crt1_owned_rows(); }
+
+int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes) { ON_ALL(crt1_upload_triangles(tris, byteOffset, bytes)); }
+int crt_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes) { ON_ALL(crt1_upload_bvh_nodes(nodes, byteOffset, bytes)); }
+int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count) { ON_ALL(crt1_upload_bvh_roots(roots, firstMesh, count)); }
+int crt_upload_materials(const void* materials, size_t first, size_t count) { ON_ALL(crt1_upload_materials(materials, first, count)); }
+int crt_upload_texture_table(const void* textures, size_t count) { ON_ALL(crt1_upload_texture_table(textures, count)); }
+int crt_upload_texels(const void* rgb8, size_t byteOffset, size_t bytes) { ON_ALL(crt1_upload_texels(rgb8, byteOffset, bytes)); }
+int crt_upload_instances(const void* instances, size_t first, size_t count) { ON_ALL(crt1_upload_instances(instances, first, count)); }
+// every device builds its own copy (the builder is deterministic: same bytes everywhere); downloads read the primary's
+int crt_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes, size_t firstNode, size_t firstMesh, uint32_t* nodesUsedOut)
+{ ON_ALL(crt1_build_bvh(firstTri, meshTriCounts, numMeshes, firstNode, firstMesh, nodesUsedOut)); }
+int crt_download_triangles(void* dst, size_t byteOffset, size_t bytes) { ON_PRIMARY(crt1_download_triangles(dst, byteOffset, bytes)); }
+int crt_download_bvh_nodes(void* dst, size_t byteOffset, size_t bytes) { ON_PRIMARY(crt1_download_bvh_nodes(dst, byteOffset, bytes)); }
+int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count) { ON_PRIMARY(crt1_download_bvh_roots(dst, firstMesh, count)); }
+
+int crt_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags)
+{
+    NEED_SESSION();
+    if (M.n == 1) { Use u(0); return crt1_render(args, invView, invProj, flags); }
+    if (!args || !invView || !invProj) return CRT_E_BAD_ARGUMENT;
+    if (flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_STAMPS)) return CRT_E_UNSUPPORTED;   // single-device diagnostics
+    // secondaries first, each on its own worker thread (they record the events the primary's stream then waits on);
+    // their copy of the frame never leaves the device except through the gather, so READBACK is the primary's business
+    struct Job { CrtTraceArgs a; float iv[16], ip[16]; int flags; } job;
+    job.a = *args; memcpy(job.iv, invView, 64); memcpy(job.ip, invProj, 64); job.flags = flags & ~CRT_RENDER_READBACK;
+    for (int d = 1; d < M.n; ++d) M.worker[d]->post([job]() { return crt1_render(&job.a, job.iv, job.ip, job.flags); });
+    int rc = CRT_OK;
+    for (int d = 1; d < M.n; ++d) { const int r = M.worker[d]->wait(); if (r != CRT_OK && rc == CRT_OK) rc = r; }
+    Use u(0);
+    const int r0 = crt1_render(args, invView, invProj, flags);
+    return rc != CRT_OK ? rc : r0;
+}
+
+int crt_sync(void) { ON_ALL(crt1_sync()); }
+
+// reads go to the primary, which holds the gathered frame -- after every device has drained
+static int drain_secondaries() { for (int d = 1; d < M.n; ++d) { Use u(d); const int r = crt1_sync(); if (r != CRT_OK) return r; } return CRT_OK; }
+int crt_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out) { ON_PRIMARY(crt1_query_hits(origins, dirs, n, numInstances, out)); }
+int crt_read_output(float* dst, size_t floats) { NEED_SESSION(); RCCHK(drain_secondaries()); ON_PRIMARY(crt1_read_output(dst, floats)); }
+int crt_read_output_rows(float* dst, int row0, int rows) { NEED_SESSION(); RCCHK(drain_secondaries()); ON_PRIMARY(crt1_read_output_rows(dst, row0, rows)); }
+int crt_read_output_rgba8(uint8_t* dst, size_t bytes) { NEED_SESSION(); RCCHK(drain_secondaries()); ON_PRIMARY(crt1_read_output_rgba8(dst, bytes)); }
+int crt_map_host_frame_back(int framesBack, const void** ptr, size_t* bytes) { ON_PRIMARY(crt1_map_host_frame_back(framesBack, ptr, bytes)); }
+int crt_map_host_frame(const void** ptr, size_t* bytes) { return crt_map_host_frame_back(0, ptr, bytes); }
+int crt_read_rays(float* dst, size_t floats) { NEED_SESSION(); if (M.n > 1) return CRT_E_UNSUPPORTED; ON_PRIMARY(crt1_read_rays(dst, floats)); }
+void* crt_output_device_ptr(void) { if (M.n == 0) return nullptr; Use u(0); return crt1_output_device_ptr(); }
+float crt_last_kernel_ms(int which) { if (M.n == 0) return -1.0f; Use u(0); return crt1_last_kernel_ms(which); }
+int crt_frame_time_stats(CrtFrameStats* out, int reset)
+{
+    NEED_SESSION();
+    for (int d = 1; d < M.n; ++d) { Use u(d); RCCHK(crt1_frame_time_stats(nullptr, reset)); }     // keeps the secondaries' event sets collected
+    ON_PRIMARY(crt1_frame_time_stats(out, reset));
+}
+int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves) { ON_PRIMARY(crt1_debug_read_stamps(dst, maxWaves, numWaves)); }
+
+// work counters of the last counted frame: the sum over the devices (maxStack: the maximum)
+int crt_get_counters(CrtCounters* out)
+{
+    NEED_SESSION();
+    if (!out) return CRT_E_BAD_ARGUMENT;
+    CrtCounters total; memset(&total, 0, sizeof total);
+    unsigned long long maxStack = 0;
+    for (int d = 0; d < M.n; ++d) {
+        Use u(d);
+        CrtCounters c;
+        RCCHK(crt1_get_counters(&c));
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&c);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&total);
+        for (size_t k = 0; k < sizeof(CrtCounters) / sizeof(unsigned long long); ++k) dst[k] += src[k];
+        if (c.maxStack > maxStack) maxStack = c.maxStack;
+    }
+    total.maxStack = maxStack;
+    *out = total;
+    return CRT_OK;
+}
+int crt_get_culled_visits(uint64_t* out)
+{
+    NEED_SESSION();
+    if (!out) return CRT_E_BAD_ARGUMENT;
+    uint64_t total = 0;
+    for (int d = 0; d < M.n; ++d) { Use u(d); uint64_t c = 0; RCCHK(crt1_get_culled_visits(&c)); total += c; }
+    *out = total;
+    return CRT_OK;
+}
 } // extern "C"

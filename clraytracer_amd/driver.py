@@ -14,13 +14,21 @@ from ._lib import CrtCounters, CrtError, CrtTraceArgs
 
 
 class Session:
-    def __init__(self, width, height, device=0, host_only=False):
+    def __init__(self, width, height, device=0, host_only=False, devices=None):
+        """device: one HIP ordinal; devices: a list of ordinals -> several GPUs in this process (Renderer::InitializeDevices;
+        the same GPU may be listed more than once to rehearse the multi-device path on a one-GPU box)."""
         self.h = _lib.host()
         self.hip = _lib.hip()
         self.width, self.height = int(width), int(height)
         self.host_only = bool(host_only)
         self.scene = None
-        ok = self.h.crth_initialize_host_only(self.width, self.height) if host_only else self.h.crth_initialize(int(device), self.width, self.height)
+        if host_only:
+            ok = self.h.crth_initialize_host_only(self.width, self.height)
+        elif devices is not None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            ok = self.h.crth_initialize_devices(ids, len(devices), self.width, self.height)
+        else:
+            ok = self.h.crth_initialize(int(device), self.width, self.height)
         if not ok:
             rc = self.h.crth_last_error()
             raise CrtError(f"Renderer::Initialize failed ({rc}): {self.hip.crt_error_string(rc).decode()}")

@@ -55,13 +55,13 @@ void Renderer::SetTime(float seconds) { timeSeconds = seconds; }
 int Renderer::LastError() { return lastError ? lastError : ResourceManager::LastError(); }
 float Renderer::LastFrameMs() { return deviceReady ? crt_last_kernel_ms(0) : -1.0f; }
 
-int Renderer::Initialize(int device, int width, int height)
+static int initialize_common(int rc, int width, int height)
 {
     lastError = 0;
     camera = Camera();
     camera.RecalculateProjection(width, height);
     camera.RecalculateView();
-    if (!check(crt_init(device, width, height), "crt_init")) return 0;
+    if (!check(rc, "crt_init")) return 0;
     deviceReady = true;
     ResourceManager::Initialize(true);
     CPU_RayTraceInitialize();
@@ -69,6 +69,15 @@ int Renderer::Initialize(int device, int width, int height)
     shouldUpdateInstances = false; MinUpdatedInstanceIndex = 0xFFFFu; MaxUpdatedInstanceIndex = 0u;
     frameIndex = 0;
     return 1;
+}
+
+int Renderer::Initialize(int device, int width, int height) { return initialize_common(crt_init(device, width, height), width, height); }
+
+// Several GPUs of the node behind the same Renderer: replicated scene, the frame tiled in 16-row bands over the devices,
+// Render() returns when the whole frame has been gathered on the first device (include/crt_api.h, crt_init_devices).
+int Renderer::InitializeDevices(const int* devices, int numDevices, int width, int height)
+{
+    return initialize_common(crt_init_devices(devices, numDevices, width, height), width, height);
 }
 
 void Renderer::OnWindowResize(int width, int height)

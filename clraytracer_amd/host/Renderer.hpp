@@ -13,6 +13,9 @@ namespace Renderer
 
     // device: HIP ordinal; width/height: initial frame (the reference takes them from the window)
     int Initialize(int device = 0, int width = 1249, int height = 720);
+    // several GPUs in this process (extension: upstream drives one device): same API afterwards, Render() delivers the
+    // whole frame; `devices` lists HIP ordinals (a GPU may be named twice to rehearse the path on a one-GPU box)
+    int InitializeDevices(const int* devices, int numDevices, int width = 1249, int height = 720);
     void Terminate();
     // one frame: RayGen -> Trace -> PostProcess -> wait (Renderer.cpp:305-375). Returns the frame
     // index (>0) or 0 on failure (see LastError()).

@@ -17,6 +17,7 @@ namespace { bool hostOnly = false; int hostOnlyError = 0; }
 extern "C" {
 
 int crth_initialize(int device, int width, int height) { hostOnly = false; return Renderer::Initialize(device, width, height); }
+int crth_initialize_devices(const int* devices, int numDevices, int width, int height) { hostOnly = false; return Renderer::InitializeDevices(devices, numDevices, width, height); }
 
 int crth_initialize_host_only(int width, int height)
 {

@@ -63,6 +63,17 @@ typedef struct CrtCounters {
  * Allocates every pool at its reference capacity once; nothing is resized later except by
  * crt_resize. */
 int crt_init(int device, int width, int height);
+/* Several GPUs of one node behind the same entry points (no reference counterpart: Renderer.cpp:134 asks
+ * clGetDeviceIDs for ONE device). The scene is replicated by every upload; the frame is cut into 16-row
+ * bands dealt round-robin to the devices; every device traces its bands on its own streams and copies them into the first
+ * device's frame (peer copies over xGMI, no collective, no host staging). crt_render keeps its meaning -- without
+ * CRT_RENDER_ASYNC it returns when the WHOLE frame is complete -- and crt_read_output / crt_map_host_frame /
+ * crt_output_device_ptr deliver the whole frame from the first device. Counters are summed over the devices.
+ * Not available in such a session: crt_set_row_bands (the bands are the library's), CRT_RENDER_WRITE_RAYS, CRT_RENDER_STAMPS.
+ * `devices` may name the same GPU more than once (functional rehearsal of the multi-device path on a one-GPU box). */
+int crt_init_devices(const int* devices, int numDevices, int width, int height);
+int crt_init_gpus(int numGpus, int width, int height);        /* devices 0 .. numGpus-1 */
+int crt_num_devices(void);                                    /* 0 = no session */
 /* Renderer.cpp:377-394, ResourceManager.cpp:303-319 */
 int crt_shutdown(void);
 /* Renderer.cpp:198-211: ignores sizes below 16 like the reference (returns CRT_OK, no change). */

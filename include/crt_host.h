@@ -15,6 +15,8 @@ extern "C" {
 
 /* Renderer::Initialize (Renderer.cpp:175). Returns 1 on success, 0 on failure (crth_last_error). */
 int crth_initialize(int device, int width, int height);
+/* Renderer::InitializeDevices: several GPUs in this process behind the same calls (crt_init_devices). */
+int crth_initialize_devices(const int* devices, int numDevices, int width, int height);
 /* Host-only session: importer, BVH build and CPU_RayCast work; crth_render fails loudly. */
 int crth_initialize_host_only(int width, int height);
 void crth_terminate(void);                                   /* Renderer::Terminate */
