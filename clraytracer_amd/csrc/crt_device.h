@@ -34,18 +34,20 @@
 #define CRT_LEAF_BIT 0x80000000u
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
 #ifndef CRT_WAVES_PER_SIMD
-#define CRT_WAVES_PER_SIMD 7   // 28 waves per CU: 72 VGPRs (the trace kernel needs 72 without SLP vectorisation) and 5 KiB of LDS each
+#define CRT_WAVES_PER_SIMD 8   // 32 waves per CU: 64 VGPRs (the trace kernel fits them without scratch) and 5 KiB of LDS each = the CU's 160 KiB
 #endif
+#define CRT_WAVES_PER_SIMD_COUNT 6   // instrumented instantiations (work counters, stamps, queries) carry 14 more registers: 80 VGPRs, no heavy spills
 // Traversal stack: upstream's `int nodesToVisit[32]` (kernel_main.cl:126), slot indices wrapping modulo 32 where
 // upstream's array would overflow. Slots 0..CRT_LDS_SLOTS-1 live in LDS -- slot s of lane l at lds[s * 64 + l], so a
-// wave's ds_read/ds_write_b32 is conflict-free; 20 slots = 5 KiB per wave, which is what lets 28 waves share a CU's
+// wave's ds_read/ds_write_b32 is conflict-free; 20 slots = 5 KiB per wave, which is what lets 32 waves share a CU's
 // 160 KiB. Slots 20..31 (no scene here has passed depth 15; hand-built deep trees in tests/test_gpu_deep_stack.py do)
 // live in a global overflow block owned by the WORKGROUP (blockIdx.x): no two waves of a launch share an entry, every
 // frame slot / query has its own area, and an entry is always written (push) before it is read (pop) within one
 // traversal, so the area needs no initialisation and costs nothing until a stack passes 20 entries.
 // (Round 1 indexed the area by the hardware wave slot from HW_ID; that is only unique while no wave is context-saved
 // and restored elsewhere. Round 1 also had two flavours, 32 LDS slots at 5 waves/SIMD and 25 at 6: the SLP vectoriser's
-// packed-math splats cost 20+ VGPRs and spilled; with -fno-slp-vectorize one 7-waves/SIMD flavour wins everywhere.)
+// packed-math splats cost 20+ VGPRs and spilled; with -fno-slp-vectorize one flavour at 8 waves/SIMD wins everywhere:
+// 5.9 -> 6.6 (no SLP, 6 waves) -> 7.0 (7 waves) -> 7.6 Gray/s (8 waves) on multi-1M with frames in flight.)
 // (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load.)
 typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
 #ifndef CRT_LDS_SLOTS

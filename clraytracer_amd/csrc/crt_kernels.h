@@ -53,9 +53,9 @@ __device__ __forceinline__ void zero_counters(LaneCounters& lc)
 // interleave row by row, which keeps them equally loaded when geometry is concentrated in one part
 // of the frame (a contiguous slab per XCD left most XCDs idle: ~1.2 resident waves/SIMD measured).
 // `slotOut` receives this workgroup's index into the per-tile cost array (or -1).
-__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, int* slotOut = nullptr, bool* quadrantOut = nullptr)
+__device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, int* slotOut = nullptr, bool* quadrantOut = nullptr, int b = blockIdx.x,
+                                           int lane = (int)(threadIdx.x & 63))
 {
-    const int b = blockIdx.x;
     const int xcd = b & 7;
     int slot = b >> 3;
     int quadrant = -1;
@@ -65,7 +65,7 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
     // launch order and the wave shape change. (Before: 0.45 ms with the machine full + 0.45 ms of tail.)
     if (F.order) {
         if ((uint32_t)slot >= F.listLen[xcd]) { if (slotOut) *slotOut = -1; return false; }
-        const uint32_t e = F.order[xcd * F.listCap + slot];
+        const uint32_t e = __builtin_amdgcn_readfirstlane(F.order[xcd * F.listCap + slot]);   // wave-uniform: keep it (and what follows from it) in SGPRs
         slot = (int)(e & 0x0FFFFFFFu);
         if (e & 0x80000000u) quadrant = (int)((e >> 28) & 3u);
         if (quadrantOut) *quadrantOut = (e & 0x80000000u) != 0;
@@ -77,7 +77,6 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
     if (k >= F.ownedTileRows) return false;
     const int bandK = k / F.tileRowsPerBand;
     const int tileRow = (F.rank + bandK * F.nRanks) * F.tileRowsPerBand + (k - bandK * F.tileRowsPerBand);
-    const int lane = threadIdx.x & 63;
     if (quadrant >= 0 && (lane >> 4) != quadrant) return false;   // Morton order: lanes 16q..16q+15 are one 4x4 quadrant
     const int lx = (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4);
     const int ly = ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4);
@@ -172,7 +171,7 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
 // product is 0 whatever the shadow factor).
 // TLAS: candidates come from the instance tree instead of the linear sphere loop (scenes with many instances).
 template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false>
-__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD)
+__global__ __launch_bounds__(CRT_BLOCK, (COUNT || STAMP) ? CRT_WAVES_PER_SIMD_COUNT : CRT_WAVES_PER_SIMD)
 void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
@@ -207,7 +206,14 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
                 ps.energy = ps.energy * specular_x(ndl, shadow);
             }
         }
-        out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+        // the pixel coordinates are recomputed here rather than kept alive through both traversals (4 VGPRs that were
+        // spilled to scratch at 8 waves/SIMD): the block index goes through an opaque asm so the two computations are
+        // not merged
+        int b2 = blockIdx.x, lane2 = (int)(threadIdx.x & 63);
+        asm volatile("" : "+s"(b2), "+v"(lane2));
+        int qx, qy;
+        (void)lane_pixel(F, qx, qy, nullptr, nullptr, b2, lane2);
+        out[(size_t)qy * (size_t)F.width + (size_t)qx] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
     }
     if (F.cost && costSlot >= 0) {      // per-tile cost of this frame (wave-uniform value, one store)
         // the four quadrant waves of a split tile each add half their cycles: about what the tile would take as one wave
@@ -241,7 +247,7 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
 struct CrtBounceRay { float ox, oy, oz, energy, dx, dy, dz; uint32_t pixel; };   // 32 B
 
 template <bool COUNT>
-__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+__global__ __launch_bounds__(CRT_BLOCK, COUNT ? CRT_WAVES_PER_SIMD_COUNT : CRT_WAVES_PER_SIMD) void crt_primary_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                                 unsigned long long* __restrict__ counters,
                                                                 CrtBounceRay* __restrict__ queue, uint32_t* __restrict__ queueCount)
 {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_primary_ker
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_bounce_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
+__global__ __launch_bounds__(CRT_BLOCK, COUNT ? CRT_WAVES_PER_SIMD_COUNT : CRT_WAVES_PER_SIMD) void crt_bounce_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out,
                                                                unsigned long long* __restrict__ counters,
                                                                const CrtBounceRay* __restrict__ queue, const uint32_t* __restrict__ queueCount)
 {
@@ -371,7 +377,7 @@ __global__ void crt_pack_unorm8_kernel(const float4* __restrict__ img, uint32_t*
 
 // closest-hit query over explicit rays (hit-record parity)
 template <bool TLAS>
-__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD_COUNT) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,
                                                               const float* __restrict__ dirs, int n,
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
