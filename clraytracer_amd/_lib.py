@@ -65,6 +65,7 @@ HIP_API = {
     "crt_resize": (C.c_int, [C.c_int, C.c_int]),
     "crt_set_row_bands": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "crt_row_owner": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "crt_band_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "crt_upload_triangles": (C.c_int, [_vp, _sz, _sz]),
     "crt_upload_bvh_nodes": (C.c_int, [_vp, _sz, _sz]),
     "crt_upload_bvh_roots": (C.c_int, [_vp, _sz, _sz]),

@@ -211,21 +211,32 @@ int alloc_frame_buffers(int w, int h)
 // Copies the pixel rows this rank owns (16-row bands dealt round-robin, crt_set_row_bands) from one frame-shaped buffer to
 // the same place in another: one strided 2-D copy (a band is contiguous, bands repeat every nRanks * bandRows rows) plus at
 // most one partial band at the bottom. Used for band-only read-backs and for the in-process multi-GPU gather.
+// The rows rank `rank` of `nRanks` owns, as one strided block list: `fullBands` bands of `bandRows` rows starting at row
+// `firstRow` and repeating every bandRows * nRanks rows, plus `tailRows` rows of a last, partial band at row `tailRow`.
+struct BandPlan { int firstRow, fullBands, tailRow, tailRows; };
+BandPlan band_plan(int height, int bandRows, int rank, int nRanks)
+{
+    BandPlan p = { rank * bandRows, 0, 0, 0 };
+    const int period = bandRows * nRanks;
+    if (p.firstRow >= height) { p.tailRow = height; return p; }
+    const int x = height - p.firstRow;
+    p.fullBands = x / period + ((x % period) >= bandRows ? 1 : 0);
+    p.tailRow = p.firstRow + p.fullBands * period;
+    p.tailRows = p.tailRow < height ? height - p.tailRow : 0;
+    return p;
+}
+
 int copy_owned_rows_async(void* dstFrame, const void* srcFrame, size_t bytesPerPixel, hipMemcpyKind kind, hipStream_t stream, bool allRows = false)
 {
     const size_t rowBytes = (size_t)g.width * bytesPerPixel;
     if (g.nRanks == 1 || allRows) return (int)hipMemcpyAsync(dstFrame, srcFrame, rowBytes * (size_t)g.height, kind, stream);
+    const BandPlan p = band_plan(g.height, g.bandRows, g.rank, g.nRanks);
     const size_t bandBytes = rowBytes * (size_t)g.bandRows, pitch = bandBytes * (size_t)g.nRanks;
-    const size_t first = (size_t)g.rank * bandBytes;                       // byte offset of this rank's first band
-    const int period = g.bandRows * g.nRanks, firstRow = g.rank * g.bandRows;
-    if (firstRow >= g.height) return CRT_OK;
-    const int fullBands = (g.height - firstRow) / period + (((g.height - firstRow) % period) >= g.bandRows ? 1 : 0);
-    char* d = static_cast<char*>(dstFrame) + first; const char* sp = static_cast<const char*>(srcFrame) + first;
-    if (fullBands > 0) HIPCHK(hipMemcpy2DAsync(d, pitch, sp, pitch, bandBytes, (size_t)fullBands, kind, stream));
-    const int tailRow = firstRow + fullBands * period;                     // a last, partial band?
-    if (tailRow < g.height) {
-        const size_t off = (size_t)fullBands * pitch, bytes = rowBytes * (size_t)(g.height - tailRow);
-        HIPCHK(hipMemcpyAsync(d + off, sp + off, bytes, kind, stream));
+    char* d = static_cast<char*>(dstFrame) + (size_t)p.firstRow * rowBytes; const char* sp = static_cast<const char*>(srcFrame) + (size_t)p.firstRow * rowBytes;
+    if (p.fullBands > 0) HIPCHK(hipMemcpy2DAsync(d, pitch, sp, pitch, bandBytes, (size_t)p.fullBands, kind, stream));
+    if (p.tailRows > 0) {
+        const size_t off = (size_t)p.fullBands * pitch;
+        HIPCHK(hipMemcpyAsync(d + off, sp + off, rowBytes * (size_t)p.tailRows, kind, stream));
     }
     return CRT_OK;
 }
@@ -1313,6 +1324,15 @@ static void destroy_group()
         delete M.dev[d]; M.dev[d] = nullptr;
     }
     G = nullptr; M.n = 0;
+}
+
+// pure: the block list a rank's gather / read-back copies (needs no device; tests/test_distributed.py)
+int crt_band_plan(int height, int bandRows, int rank, int nRanks, int out[4])
+{
+    if (!out || height < 0 || bandRows < CRT_TILE || bandRows % CRT_TILE != 0 || nRanks < 1 || rank < 0 || rank >= nRanks) return CRT_E_BAD_ARGUMENT;
+    const BandPlan p = band_plan(height, bandRows, rank, nRanks);
+    out[0] = p.firstRow; out[1] = p.fullBands; out[2] = p.tailRow; out[3] = p.tailRows;
+    return CRT_OK;
 }
 
 int crt_init_devices(const int* devices, int numDevices, int width, int height)

@@ -84,6 +84,10 @@ int crt_resize(int width, int height);
 int crt_set_row_bands(int bandRows, int rank, int nRanks);
 /* Which rank renders frame row `row` under that tiling (pure function, needs no device). */
 int crt_row_owner(int row, int bandRows, int nRanks);
+/* The rows a rank owns as the block list its gather / read-back copies use (pure function): out = { firstRow, fullBands,
+ * tailRow, tailRows }: `fullBands` bands of bandRows rows from firstRow, every bandRows * nRanks rows, then tailRows rows
+ * of a last partial band at tailRow. */
+int crt_band_plan(int height, int bandRows, int rank, int nRanks, int out[4]);
 
 /* ResourceManager.cpp:286 -- triangles in the 80-byte reference layout, offsets in bytes. */
 int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes);

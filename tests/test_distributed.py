@@ -87,3 +87,72 @@ def test_algorithmic_bytes_formula():
     import bench
     c = dict(innerVisits=10, triTests=3, traversals=2, hits=1, misses=1)
     assert bench.algorithmic_bytes(c, 4) == 64 * 10 + 48 * 3 + 80 * 2 + 214 + 19 + 16 * 4
+
+
+def test_band_plan_partitions_every_frame():
+    """crt_band_plan (the block list behind the multi-GPU gather and the band-only read-back) against crt_row_owner, for
+    ragged heights, several band heights and rank counts: the plans of all ranks tile the frame exactly once."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    from clraytracer_amd import _lib
+    hip = _lib.hip()
+    for height in (16, 17, 48, 200, 360, 1080, 2160, 2161):
+        for band in (8, 16, 32):
+            for n in (1, 2, 3, 4, 8):
+                seen = np.zeros(height, np.int32)
+                for r in range(n):
+                    out = (C.c_int * 4)()
+                    assert hip.crt_band_plan(height, band, r, n, out) == 0
+                    first, full, tail_row, tail_rows = list(out)
+                    rows = [first + k * band * n + j for k in range(full) for j in range(band)] + [tail_row + j for j in range(tail_rows)]
+                    assert all(0 <= y < height and hip.crt_row_owner(y, band, n) == r for y in rows), (height, band, n, r)
+                    seen[rows] += 1
+                assert (seen == 1).all(), (height, band, n)
+    assert hip.crt_band_plan(100, 12, 0, 2, (C.c_int * 4)()) != 0          # band height must be a multiple of the tile height
+
+
+def _gather_worker(rank, world, port, outdir):
+    """Each rank fills the rows crt_band_plan gives it in its own frame-shaped buffer, then the bands travel to rank 0 with
+    point-to-point sends that follow the same block list (what hipMemcpy2DAsync does between devices in crt_init_devices
+    sessions): rank 0 must end up with the whole frame."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import ctypes as C
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clraytracer_amd import _lib
+        hip = _lib.hip()
+        Hh, Ww = 90, 40                                              # 5.6 bands of 16 rows: a partial band at the bottom
+        truth = torch.arange(Hh * Ww * 4, dtype=torch.float32).reshape(Hh, Ww, 4)
+
+        def blocks(r):
+            out = (C.c_int * 4)()
+            assert hip.crt_band_plan(Hh, BAND, r, world, out) == 0
+            first, full, tail_row, tail_rows = list(out)
+            return [(first + k * BAND * world, BAND) for k in range(full)] + ([(tail_row, tail_rows)] if tail_rows else [])
+
+        frame = torch.zeros(Hh, Ww, 4)
+        for y0, n in blocks(rank):
+            frame[y0:y0 + n] = truth[y0:y0 + n]                     # "render" the owned bands
+        if rank == 0:
+            for src in range(1, world):
+                for y0, n in blocks(src):
+                    buf = torch.empty(n, Ww, 4)
+                    dist.recv(buf, src=src)
+                    frame[y0:y0 + n] = buf
+            assert torch.equal(frame, truth)
+            np.save(os.path.join(outdir, "gathered.npy"), frame.numpy())
+        else:
+            for y0, n in blocks(rank):
+                dist.send(frame[y0:y0 + n].contiguous(), dst=0)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_follows_the_band_plan(tmp_path):
+    world = 2
+    port = 29100 + (os.getpid() % 500)
+    mp.spawn(_gather_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    assert np.array_equal(got, np.arange(90 * 40 * 4, dtype=np.float32).reshape(90, 40, 4))
