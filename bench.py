@@ -28,9 +28,10 @@ The JSON line also carries
                  inner visits + 48 B x triangle tests + 80 B x instance records + fixed per-hit / per-miss / per-pixel
                  bytes) are reported next to it as `algorithmic_*`: they exceed what reaches HBM many times over (the
                  hot data sits in L1/L2/Infinity Cache), so their rate is not a fraction of any roofline.
-                 `gather` is the bound that does hold for this kernel: real (post-cull) 64-B child-pair fetches per
-                 cycle per CU against the microbenchmarked ceiling for divergent 64-B gathers served from L2
-                 (tools/ubench/gather.hip, profiles/r01_ubench_gather.txt).
+                 `gather`: real (post-cull) 64-B child-pair fetches per cycle per CU against the vector-memory pipeline's
+                 ceiling for such fetches (tools/ubench/gather.hip), with the fully-divergent-from-L2 rate as a reference
+                 point; `valu`: VALU issue occupancy and lane utilisation from the committed SQ PMC passes -- the
+                 resource this kernel is closest to saturating.
   cpu_baseline : the reference's CPU path timed on this box's host cores (rank 0, N == 1 only): the mirrored
                  CPU_RayCast (CPURayTrace.cpp:186-249, SSE flavour with upstream's rcpps/dpps instruction mix) over the
                  primary rays of the bench frame at 1 thread and at all usable cores, and the scalar Trace oracle
@@ -57,9 +58,13 @@ def algorithmic_bytes(c, pixels):
     return per_ray + per_hit + per_miss + per_pixel
 
 
-# tools/ubench/gather.hip on MI355X (profiles/r01_ubench_gather.txt): fully divergent 64-B-per-lane gathers, table
-# resident in L2: 181 cycles per wave-level fetch of 64 records per CU -> 0.354 records per cycle per CU
-GATHER_CEILING_L2 = 64.0 / 181.0
+# tools/ubench/gather.hip on MI355X (profiles/r02_ubench_gather.txt), 64-B-per-lane record fetches as 4 x 16-B loads:
+#  * every lane of a wave reads the SAME L1-resident record: 17 cycles per wave-level fetch per CU -> 3.76 records per
+#    cycle per CU. Nothing a traversal does can beat that: the ceiling `gather.frac` is taken against.
+#  * every lane reads a DIFFERENT record of a table resident in L2: 181 cycles -> 0.354 records per cycle per CU; a
+#    reference point, not a bound -- coherent packets (many lanes on one line, L1 hits) legitimately run above it.
+GATHER_CEILING_UNIFORM = 64.0 / 17.0
+GATHER_DIVERGENT_L2 = 64.0 / 181.0
 
 
 def usable_cpus():
@@ -99,6 +104,26 @@ def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device, group=No
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     tot = dict(zip(COUNTER_KEYS + ["pixels", "alg_bytes"], vec.tolist()))
     return tot, tmax[0].item(), tmax[1].item()
+
+
+def pmc_valu(kernel, workload_scene, width, height):
+    """VALU issue-slot occupancy and lane utilisation of the dominant kernel from the committed SQ PMC passes
+    (profiles/*_summary.json `derived`), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            b = d.get("bench_line") or {}
+            dv = d.get("derived", {})
+            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene \
+                    and b["config"].get("width") == width and b["config"].get("height") == height and "valu_issue_busy" in dv:
+                return {"issue_busy": round(dv["valu_issue_busy"], 3), "lane_utilisation": round(dv["valu_lane_utilisation"], 3),
+                        "source": os.path.relpath(path, ROOT),
+                        "note": "SQ_ACTIVE_INST_VALU / (SIMDs x busy quad-cycles) and SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): "
+                                "the resource this kernel is closest to saturating"}
+        except Exception:
+            continue
+    return None
 
 
 def pmc_traffic(kernel, workload_scene, width, height):
@@ -329,6 +354,7 @@ def main():
         achieved = None if traffic is None else traffic / dev_s / 1e9
         frac = None if achieved is None else achieved / HBM_PEAK_GBS
         assert frac is None or frac <= 1.0, f"measured HBM traffic rate {achieved} GB/s exceeds the peak: profile does not belong to this run"
+        assert pair_fetches / (dev_s * 2.4e9 * 256) <= GATHER_CEILING_UNIFORM
         clock_ghz = float(os.environ.get("CRT_SCLK_GHZ", "2.4"))             # MI355X peak engine clock (MI355X_MICROARCH.md)
         num_cus = int(hip.crt_device_name().decode().split(",")[-1].split()[0])
         gather_rate = pair_fetches / (dev_s * clock_ghz * 1e9 * num_cus)       # 64-B records per cycle per CU
@@ -363,10 +389,14 @@ def main():
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
                          "inner_visits_per_ray": round(cnt["innerVisits"] / max(1, cnt["rays"]), 2),
                          "tri_tests_per_ray": round(cnt["triTests"] / max(1, cnt["rays"]), 2),
-                         "gather": {"bound": "divergent 64-B record gathers served from L2, records per cycle per CU (tools/ubench/gather.hip)",
+                         "gather": {"bound": "64-B child-pair records fetched per cycle per CU; ceiling = every lane of a wave on one L1-resident record (tools/ubench/gather.hip)",
                                     "pair_fetches_per_launch": int(pair_fetches), "culled_root_visits_per_launch": int(culled.value),
-                                    "achieved": round(gather_rate, 4), "ceiling": round(GATHER_CEILING_L2, 4),
-                                    "frac": round(gather_rate / GATHER_CEILING_L2, 4), "clock_ghz": clock_ghz, "cus": num_cus}},
+                                    "achieved": round(gather_rate, 4), "ceiling": round(GATHER_CEILING_UNIFORM, 4),
+                                    "frac": round(gather_rate / GATHER_CEILING_UNIFORM, 4),
+                                    "divergent_l2_reference": round(GATHER_DIVERGENT_L2, 4),
+                                    "ratio_to_divergent_l2": round(gather_rate / GATHER_DIVERGENT_L2, 4),
+                                    "clock_ghz": clock_ghz, "cus": num_cus},
+                         "valu": pmc_valu("crt_trace_kernel", sc.name, width, height) if (n == 1 and not args.shadows) else None},
         }
         if sync_elapsed is not None:
             out["synchronous_frames"] = {"value": round(rays_per_frame * args.steps / sync_elapsed / 1e6, 2), "unit": "Mrays/s",

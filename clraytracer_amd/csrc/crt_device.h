@@ -615,9 +615,14 @@ __device__ __forceinline__ float specular_x(float ndl, float shadow)
 
 // DEFER_ENERGY (CRT_RENDER_SHADOWS): leave `energy *= specular` to the caller, which first traces the shadow ray
 // from the new ray origin; `ndlOut` receives the clamped n.l that decides whether the shadow factor is observable.
-template <bool DEFER_ENERGY = false>
-__device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest& c, PathState& ps, int bounce, float lightY, float lightZ,
-                                             float* ndlOut = nullptr)
+// REFRACT (CRT_RENDER_REFRACTION, an extension defined by the oracle, oracle/crt_oracle.h): at the first hit of a material
+// whose opacity (MTL `d`, kept in Material::roughness) is below 1 the continuing ray is the refracted one (Snell, index
+// 1.5; total internal reflection keeps the reflection), 0.01 behind the surface, with (1 - opacity) of the energy.
+// Returns 0: path ended (miss -> skybox); 1: continues with the reflected ray; 2: continues with the transmitted ray
+// (energy already applied, no shadow ray wanted).
+template <bool DEFER_ENERGY = false, bool REFRACT = false>
+__device__ __forceinline__ int shade_bounce(const CrtDevScene& S, const Closest& c, PathState& ps, int bounce, float lightY, float lightZ,
+                                            float* ndlOut = nullptr)
 {
     const float UcharToFloat01 = 1.0f / 255.0f;
     if (c.distance > 99998.0f) {
@@ -626,7 +631,7 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
         uint32_t px = S.texels[idx];
         v3 skyc = scale3(mk3((float)(px & 0xffu), (float)((px >> 8) & 0xffu), (float)((px >> 16) & 0xffu)), UcharToFloat01);
         ps.result = add3(ps.result, scale3(skyc, ps.energy));
-        return false;
+        return 0;
     }
     const v3 light = bounce == 0 ? mk3(0.0f, lightY, lightZ) : ps.d;     // lightDir = ray.direction after the first bounce
     const v3 atm0 = scale3(mk3(0.255f, 0.25f, 0.27f), 1.0f);
@@ -666,8 +671,32 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
     const v3 point = add3(mo, scale3(md, c.hit.t));
 
 
-    ps.o = add3(point, scale3(normal, 0.01f));
-    ps.d = reflect3(ps.d, normal);
+    bool transmitted = false;
+    float opacity = 1.0f;
+    if (REFRACT) {
+        if (bounce == 0) {
+            opacity = h2f(mat.roughness);
+            if (opacity < 1.0f) {
+                const float dn = dot3(normal, ps.d);
+                const bool entering = dn < 0.0f;
+                const v3 nf = entering ? normal : neg3(normal);
+                const float cosi = entering ? (0.0f - dn) : dn;
+                const float eta = entering ? 0.6666667f : 1.5f;
+                const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+                if (k >= 0.0f) {
+                    const float w = eta * cosi - sqrtf(k);
+                    const v3 refr = add3(scale3(ps.d, eta), scale3(nf, w));
+                    ps.o = sub3(point, scale3(nf, 0.01f));
+                    ps.d = refr;
+                    transmitted = true;
+                }
+            }
+        }
+    }
+    if (!transmitted) {
+        ps.o = add3(point, scale3(normal, 0.01f));
+        ps.d = reflect3(ps.d, normal);
+    }
 
     float ndl = dot3(normal, neg3(light));
     const v3 ambient = mul3(scale3(atm, fmaxf(0.0f - ndl, 0.1f)), color);
@@ -676,7 +705,8 @@ __device__ __forceinline__ bool shade_bounce(const CrtDevScene& S, const Closest
     const float sl = (ndl * fmaxf(dot3(reflect3(neg3(light), normal), md), 0.0f)) * 0.2f;
 
     ps.result = add3(ps.result, add3(add3(scale3(scale3(color, ndl), ps.energy), ambient), mk3(sl, sl, sl)));
+    if (REFRACT && transmitted) { ps.energy = ps.energy * (1.0f - opacity); return 2; }
     if (DEFER_ENERGY) *ndlOut = ndl;
     else ps.energy = ps.energy * specular_x(ndl, 1.0f);      // shadow = 1.0f (kernel_main.cl:258: no shadow ray upstream)
-    return true;
+    return 1;
 }

@@ -170,7 +170,8 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
 // where it is observable: at bounce 0 (the energy after bounce 1 is never read) and when n.l > 0 (otherwise the
 // product is 0 whatever the shadow factor).
 // TLAS: candidates come from the instance tree instead of the linear sphere loop (scenes with many instances).
-template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false>
+// REFRACT (CRT_RENDER_REFRACTION, the other README TODO of upstream, oracle-defined): translucent materials transmit.
+template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false, bool REFRACT = false>
 __global__ __launch_bounds__(CRT_BLOCK, (COUNT || STAMP) ? CRT_WAVES_PER_SIMD_COUNT : CRT_WAVES_PER_SIMD)
 void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
@@ -193,10 +194,10 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
             Closest c = closest_hit<COUNT, STAMP, false, TLAS>(S, ps.o, ps.d, stack, lc, F.smallPacket);
             float ndl = 0.0f;
-            bool cont = shade_bounce<SHADOW>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
+            const int cont = shade_bounce<SHADOW, REFRACT>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
             if (!cont) break;
-            if (SHADOW) {
+            if (SHADOW && cont == 1) {
                 float shadow = 1.0f;
                 if (bounce == 0 && ndl > 0.0f) {
                     if (COUNT) { lc.rays++; lc.shadowRays++; }
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(CRT_BLOCK, COUNT ? CRT_WAVES_PER_SIMD_COUNT : CRT_W
         ps.d = raygen_dir(F, px, py);
         if (COUNT) { lc.rays++; lc.primary++; }
         Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc, F.smallPacket);
-        cont = shade_bounce(S, c, ps, 0, F.lightY, F.lightZ);
+        cont = shade_bounce(S, c, ps, 0, F.lightY, F.lightZ) != 0;
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
     }
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(CRT_BLOCK, COUNT ? CRT_WAVES_PER_SIMD_COUNT : CRT_W
         ps.result = mk3(partial.x, partial.y, partial.z);
         if (COUNT) { lc.rays++; lc.secondary++; }
         Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc, F.smallPacket);
-        const bool cont = shade_bounce(S, c, ps, 1, F.lightY, F.lightZ);
+        const bool cont = shade_bounce(S, c, ps, 1, F.lightY, F.lightZ) != 0;
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[r.pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
     }

@@ -923,15 +923,17 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
         }
     } else {
-        // default megakernel: <COUNT, STAMP, SHADOW, TLAS>
-        const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0;
+        // default megakernel: <COUNT, STAMP, SHADOW, TLAS, REFRACT>
+        const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, refract = (flags & CRT_RENDER_REFRACTION) != 0;
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
         const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
-#define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) crt_trace_kernel<C_, false, S_, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
-                                      else crt_trace_kernel<C_, false, S_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
+#define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) crt_trace_kernel<C_, false, S_, T_, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
+                                           else crt_trace_kernel<C_, false, S_, T_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
+#define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) CRT_LAUNCH_TRACE2(C_, S_, true); else CRT_LAUNCH_TRACE2(C_, S_, false); } while (0)
         if (count) { if (shadow) CRT_LAUNCH_TRACE(true, true); else CRT_LAUNCH_TRACE(true, false); }
         else       { if (shadow) CRT_LAUNCH_TRACE(false, true); else CRT_LAUNCH_TRACE(false, false); }
 #undef CRT_LAUNCH_TRACE
+#undef CRT_LAUNCH_TRACE2
     }
     HIPCHK(hipGetLastError());
     return CRT_OK;
@@ -952,7 +954,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // overlap (each slot has its own stream, output buffer and launch lists). Everything else -- synchronous frames,
     // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
     const bool variant = g.wavefront != 0;
-    if ((flags & CRT_RENDER_SHADOWS) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
+    if ((flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION)) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
     const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
                         && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
     int slot = 0;

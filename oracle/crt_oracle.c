@@ -376,8 +376,9 @@ static void stats_add(OrcStats* a, const OrcStats* b)
  * kernel_main.cl:164-275  Trace, one pixel
  * ---------------------------------------------------------------------------------------- */
 static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, float lightY, float lightZ,
-                        float out[4], OrcStats* st, int shadows)
+                        float out[4], OrcStats* st, int extensions)
 {
+    const int shadows = extensions & ORC_EXT_SHADOWS, refraction = extensions & ORC_EXT_REFRACTION;
     Ray ray = { f3_make(args->cameraPos[0], args->cameraPos[1], args->cameraPos[2]), rayDir };
     f3 lightDir = f3_make(0.0f, lightY, lightZ);
     f3 result = f3_make(0.0f, 0.0f, 0.0f);
@@ -427,9 +428,37 @@ static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, 
         float roughness = 0.5f;
         float shininess = 1.0f;
 
-        ray.origin = point;
-        ray.origin = f3_add(ray.origin, f3_scale(normal, 0.01f));
-        ray.direction = f3_reflect(ray.direction, normal);
+        /* EXTENSION (refraction != 0; upstream: a README TODO with no code). A material whose MTL `d` (dissolve = opacity,
+         * stored by the importer in Material::roughness, AssetManager.cpp:152-156) is below 1 transmits: at the FIRST hit the
+         * continuing ray is the refracted ray instead of the reflected one -- Snell with a fixed index 1.5 (the importer does
+         * not read `Ni`), entering when the ray runs against the normal, leaving otherwise; on total internal reflection the
+         * reflected ray is kept. The origin steps 0.01 THROUGH the surface, and the next bounce carries (1 - opacity) of the
+         * energy instead of upstream's `specular` term. Everything else in the shading of this hit is upstream's. */
+        int transmitted = 0;
+        float opacity = 1.0f;
+        if (refraction && numBounces == 0) {
+            opacity = orc_half_to_float(material->roughness);
+            if (opacity < 1.0f) {
+                const float dn = f3_dot(normal, ray.direction);
+                const int entering = dn < 0.0f;
+                const f3 nf = entering ? normal : f3_neg(normal);
+                const float cosi = entering ? (0.0f - dn) : dn;
+                const float eta = entering ? 0.6666667f : 1.5f;
+                const float k = 1.0f - (eta * eta) * (1.0f - cosi * cosi);
+                if (k >= 0.0f) {
+                    const float w = eta * cosi - sqrtf(k);
+                    const f3 refr = f3_add(f3_scale(ray.direction, eta), f3_scale(nf, w));
+                    ray.origin = f3_sub(point, f3_scale(nf, 0.01f));
+                    ray.direction = refr;
+                    transmitted = 1;
+                }
+            }
+        }
+        if (!transmitted) {
+            ray.origin = point;
+            ray.origin = f3_add(ray.origin, f3_scale(normal, 0.01f));
+            ray.direction = f3_reflect(ray.direction, normal);
+        }
 
         float shadow = 1.0f; /* upstream: "todo shadow for only directional light" (kernel_main.cl:258) */
 
@@ -439,7 +468,7 @@ static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, 
         /* EXTENSION (shadows != 0): the commented-out `shadowRay = CreateRay(ray.origin, -lightDir)` of
          * kernel_main.cl:257. `shadow` only scales `specular`, i.e. the energy of the NEXT bounce, so the ray is traced
          * only where that is observable: at the first bounce and when ndl > 0 (else the product is 0 or NaN anyway). */
-        if (shadows && numBounces == 0 && ndl > 0.0f) {
+        if (shadows && !transmitted && numBounces == 0 && ndl > 0.0f) {   /* a transmitted ray's energy does not use `shadow` */
             Ray shadowRay = { ray.origin, f3_neg(lightDir) };
             st->rays++; st->shadowRays++;
             if (occluded(s, shadowRay, args->numMeshes, st)) { shadow = 0.0f; st->shadowHits++; }
@@ -450,7 +479,7 @@ static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, 
         f3 specularLighting = f3_make(sl, sl, sl);
 
         result = f3_add(result, f3_add(f3_add(f3_mul(energy, f3_scale(color, ndl)), ambient), specularLighting));
-        energy = f3_mul(energy, specular);
+        energy = transmitted ? f3_scale(energy, 1.0f - opacity) : f3_mul(energy, specular);
         atmosphericLight = f3_scale(atmosphericLight, 0.4f);
 
         lightDir = ray.direction;
@@ -465,7 +494,7 @@ void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, i
 }
 
 void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
-                  int row0, int row1, float* out, OrcStats* stats, int nthreads, int shadows)
+                  int row0, int row1, float* out, OrcStats* stats, int nthreads, int extensions)
 {
     (void)height;
     const float lightY = (float)sin((double)args->sunAngle);
@@ -480,7 +509,7 @@ void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays
             for (int i = 0; i < width; ++i) {
                 size_t idx = (size_t)j * (size_t)width + (size_t)i;
                 f3 d = f3_make(rays[3 * idx], rays[3 * idx + 1], rays[3 * idx + 2]);
-                trace_pixel(s, args, d, lightY, lightZ, out + 4 * idx, &st, shadows);
+                trace_pixel(s, args, d, lightY, lightZ, out + 4 * idx, &st, extensions);
             }
         }
 #pragma omp critical

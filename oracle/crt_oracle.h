@@ -109,8 +109,15 @@ void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, i
  * commented-out TODO with `shadow = 1.0f` threaded into kernel_main.cl:264 -- so this mode has no reference
  * behaviour to match; it is defined here (origin = the bounce ray's origin, direction = -lightDir, any-hit over the
  * same instance loop, traced at the first bounce when n.l > 0) and the HIP path must match it bit for bit. */
+/* `extensions` = ORC_EXT_SHADOWS | ORC_EXT_REFRACTION (0 = upstream's Trace). ORC_EXT_REFRACTION: the other README TODO
+ * of upstream ("refraction", "transculency"), equally without reference behaviour and equally defined here: at the first
+ * hit of a material whose MTL `d` (opacity, kept in Material::roughness by the importer) is below 1, the continuing ray
+ * is the refracted ray (Snell, index 1.5; total internal reflection keeps the reflected ray), starting 0.01 behind the
+ * surface and carrying (1 - opacity) of the energy; no shadow ray is traced for such a hit (its factor is not used). */
+#define ORC_EXT_SHADOWS 1
+#define ORC_EXT_REFRACTION 2
 void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
-                  int row0, int row1, float* out, OrcStats* stats, int nthreads, int shadows);
+                  int row0, int row1, float* out, OrcStats* stats, int nthreads, int extensions);
 void orc_postprocess(float* rgba, int width, int height, int row0, int row1);
 /* Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef), in place on a
  * float frame; and the bytes themselves. Upstream's displayed frame = pack(postprocess(quantize(trace))). */

@@ -95,7 +95,7 @@ class Oracle:
         lib().orc_raygen(rays.ctypes.data, width, height, p1, p2)
         return rays
 
-    def trace(self, rays, cam_pos, sun_angle, row0=0, row1=None, shadows=False):
+    def trace(self, rays, cam_pos, sun_angle, row0=0, row1=None, shadows=False, refraction=False):
         h, w, _ = rays.shape
         row1 = h if row1 is None else row1
         out = np.zeros((h, w, 4), np.float32)
@@ -105,7 +105,7 @@ class Oracle:
         st = OrcStats()
         rays = np.ascontiguousarray(rays, np.float32)
         lib().orc_trace_ex(C.byref(self.s), C.byref(args), rays.ctypes.data, w, h, row0, row1, out.ctypes.data, C.byref(st), self.nthreads,
-                           1 if shadows else 0)
+                           (1 if shadows else 0) | (2 if refraction else 0))
         return out, st.as_dict()
 
     def postprocess(self, img, row0=0, row1=None):

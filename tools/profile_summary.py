@@ -66,6 +66,9 @@ def main():
         d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
         d["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / max(1.0, c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines (cycles); SQ_ACTIVE_INST_VALU over the 1024 SIMDs (quad-cycles)
+        d["valu_issue_busy"] = c["SQ_ACTIVE_INST_VALU"] / max(1.0, 1024.0 * (c["SQ_BUSY_CYCLES"] / 32.0) / 4.0)
     if "SQ_WAVE_CYCLES" in c and "SQ_WAVES" in c:
         d["wave_quad_cycles_per_wave"] = c["SQ_WAVE_CYCLES"] / max(1.0, c["SQ_WAVES"])
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:

@@ -1,0 +1,19 @@
+#!/bin/bash
+# GPU-box side: everything profiles/<tag>_* is made from, in one call.
+#   tools/run_round_evidence.sh r02   -> gpurun_out/{prof_<tag>_*, <tag>_bench_lines.jsonl, <tag>_wave_timeline.txt, <tag>_cpu_baseline.md, <tag>_ubench_gather.txt}
+tag=${1:-r02}
+out=gpurun_out
+tools/run_profiles.sh $tag 2>&1 | tail -2
+: > $out/${tag}_bench_lines.jsonl
+python bench.py >> $out/${tag}_bench_lines.jsonl 2>$out/${tag}_bench.err
+for sc in multi-1M-dense sponza-sibenik nanosuit-demo sponza-class-250k cornell-1k; do
+  python bench.py --scene $sc --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
+done
+python bench.py --shadows --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
+python bench.py --width 3840 --height 2160 --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
+python bench.py --frames-in-flight 1 --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
+python tools/wave_timeline.py multi-1M 1920 1080 > $out/${tag}_wave_timeline.txt 2>&1
+CRT_TL_RANKS=8 python tools/wave_timeline.py multi-1M 3840 2160 >> $out/${tag}_wave_timeline.txt 2>&1
+python tools/cpu_baseline.py > $out/${tag}_cpu_baseline.md 2>&1
+timeout -k 10 120 tools/ubench/gather > $out/${tag}_ubench_gather.txt 2>&1
+echo evidence done

@@ -36,7 +36,7 @@ print(f"{name} {w}x{h}: kernel {ms * 1e3:.1f} us (events), {len(st)} waves stamp
 print("wave duration us: mean %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
 print("shader cycles per wave: mean %.0f max %d ; clock ~ %.2f GHz" % (st[:, 2].mean(), st[:, 2].max(), np.median(st[:, 2].astype(np.float64) / np.maximum(dur, 1e-3)) / 1e3))
 edges = np.linspace(0, end.max(), 21)
-print("time slice (us) : resident waves (avg)   [capacity 256 CUs x 28 = 7168]")
+print("time slice (us) : resident waves (avg)   [the stamped instantiation runs 6 waves/SIMD: capacity 256 CUs x 24 = 6144; the plain kernel 8: 8192]")
 for a, b in zip(edges[:-1], edges[1:]):
     ov = np.clip(np.minimum(end, b) - np.maximum(start, a), 0, None).sum() / (b - a)
     print(f"  {a:7.1f}-{b:7.1f}: {ov:7.0f}")
