@@ -170,9 +170,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = args.gpus
-    if world != n:
-        if world == 1 and n > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # --gpus N>1 WITHOUT a launcher: all N GPUs are driven from this one process through crt_init_devices (replicated scene,
+    # 16-row bands per device, peer-copy gather into GPU 0's frame: every timed frame ends as a whole frame on one device).
+    inproc = world == 1 and n > 1
+    if world != n and not inproc:
         n = world
 
     flight = max(1, min(4, args.frames_in_flight))
@@ -225,6 +226,15 @@ def main():
         red_device = "cuda" if ctl is not None else "cpu"
         control_plane = "rccl" if ctl is not None else "gloo"
 
+    inproc_devices = None
+    if inproc:
+        have = torch.cuda.device_count()
+        if rehearse:
+            inproc_devices = [0] * n
+        elif have >= n:
+            inproc_devices = list(range(n))
+        else:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (CRT_BENCH_REHEARSE=1 lists GPU 0 {n} times: functional rehearsal)")
     width = args.width or (1920 if n == 1 else 3840)
     height = args.height or (1080 if n == 1 else 2160)
     # scene files are generated once (rank 0) into the shared cache directory
@@ -235,10 +245,28 @@ def main():
     if rank != 0:
         sc = scenes.get(args.scene)
 
+    single = None
+    if inproc:
+        # the same workload on ONE GPU first (own session: the library drives one session at a time)
+        with driver.Session(width, height, device=inproc_devices[0]) as s1:
+            s1.load_scene(sc)
+            a1, iv1, ip1 = s1.trace_args()
+            fp1 = C.POINTER(C.c_float)
+            hip1 = _lib.hip()
+            fl1 = (4 if flight > 1 else 0) | (32 if args.shadows else 0)
+            for _ in range(3):
+                _lib.check(hip1.crt_render(C.byref(a1), iv1.ctypes.data_as(fp1), ip1.ctypes.data_as(fp1), fl1), "crt_render")
+            _lib.check(hip1.crt_sync(), "crt_sync")
+            t0 = time.perf_counter()
+            for _ in range(10):
+                hip1.crt_render(C.byref(a1), iv1.ctypes.data_as(fp1), ip1.ctypes.data_as(fp1), fl1)
+            _lib.check(hip1.crt_sync(), "crt_sync")
+            single = (time.perf_counter() - t0) / 10
     t_load = time.time()
-    s = driver.Session(width, height, device=device_index)
+    s = driver.Session(width, height, device=device_index, devices=inproc_devices)
     s.load_scene(sc)
-    s.set_row_bands(args.band_rows, rank, n)
+    if not inproc:
+        s.set_row_bands(args.band_rows, rank, n)
     t_load = time.time() - t_load
 
     # instrumented launch (untimed): rays and work counters of this rank's share of the frame
@@ -266,8 +294,7 @@ def main():
 
     # N > 1: the same workload on ONE GPU (this rank renders the whole frame, untimed by the contract clock), so the
     # line carries its own strong-scaling reference next to the N-GPU value
-    single = None
-    if n > 1 and rank == 0:
+    if n > 1 and rank == 0 and not inproc:
         s.set_row_bands(args.band_rows, 0, 1)
         for _ in range(3):
             _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
@@ -318,7 +345,7 @@ def main():
     # stops. The headline above leaves the tiles in each rank's HBM; this is the rate at which a whole frame reaches
     # one place (host memory of the node) that a consumer can read.
     deliver_elapsed = None
-    if n > 1:
+    if n > 1 and not inproc:
         dflags = flags | 128
         ptr, nbytes = C.c_void_p(), C.c_size_t()
         for _ in range(min(args.warmup, 3)):
@@ -354,10 +381,11 @@ def main():
         achieved = None if traffic is None else traffic / dev_s / 1e9
         frac = None if achieved is None else achieved / HBM_PEAK_GBS
         assert frac is None or frac <= 1.0, f"measured HBM traffic rate {achieved} GB/s exceeds the peak: profile does not belong to this run"
-        assert pair_fetches / (dev_s * 2.4e9 * 256) <= GATHER_CEILING_UNIFORM
+        assert pair_fetches / (n if inproc else 1) / (dev_s * 2.4e9 * 256) <= GATHER_CEILING_UNIFORM
         clock_ghz = float(os.environ.get("CRT_SCLK_GHZ", "2.4"))             # MI355X peak engine clock (MI355X_MICROARCH.md)
         num_cus = int(hip.crt_device_name().decode().split(",")[-1].split()[0])
-        gather_rate = pair_fetches / (dev_s * clock_ghz * 1e9 * num_cus)       # 64-B records per cycle per CU
+        ndev_here = n if inproc else 1                                          # in-process: counters are summed over the devices
+        gather_rate = pair_fetches / ndev_here / (dev_s * clock_ghz * 1e9 * num_cus)   # 64-B records per cycle per CU
         out = {
             "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -368,7 +396,9 @@ def main():
                        "scene": sc.name, "width": width, "height": height, "rays_per_frame": int(rays_per_frame),
                        "primary": int(tot["primary"]), "secondary": int(tot["secondary"]), "shadow": int(tot["shadowRays"]),
                        "primary_hit_fraction": round(tot["secondary"] / max(1.0, tot["primary"]), 4),
-                       "tiling": f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
+                       "tiling": (f"16-row bands round-robin over {n} devices driven by ONE process (crt_init_devices {inproc_devices}), replicated scene, "
+                                  "every frame gathered into device 0 by peer copies inside the timed region") if inproc
+                                 else f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
                        "frames_in_flight": flight, "control_plane": control_plane,
                        "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2)},
             "inner_visits_per_s": round(tot["innerVisits"] * args.steps / elapsed_max, 0),

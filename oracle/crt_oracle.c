@@ -385,7 +385,8 @@ static void trace_pixel(const OrcScene* s, const CrtTraceArgs* args, f3 rayDir, 
     f3 energy = f3_make(1.0f, 1.0f, 1.0f);
     f3 atmosphericLight = f3_scale(f3_make(0.255f, 0.25f, 0.27f), 1.0f);
 
-    for (int numBounces = 0; numBounces < 2; ++numBounces) {
+    const int bounces = (extensions & ORC_EXT_PRIMARY_ONLY) ? 1 : 2;     /* analysis only (orc_trace_costs) */
+    for (int numBounces = 0; numBounces < bounces; ++numBounces) {
         st->rays++;
         if (numBounces == 0) st->primary++; else st->secondary++;
         Closest c = closest_hit(s, ray, args->numMeshes, st);
@@ -522,6 +523,12 @@ void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays
 void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                      uint32_t* innerOut, uint32_t* triOut, int nthreads)
 {
+    orc_trace_costs_ex(s, args, rays, width, height, innerOut, triOut, nthreads, 0);
+}
+
+void orc_trace_costs_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
+                        uint32_t* innerOut, uint32_t* triOut, int nthreads, int extensions)
+{
     const float lightY = (float)sin((double)args->sunAngle);
     const float lightZ = (float)cos((double)args->sunAngle);
     if (nthreads < 1) nthreads = 1;
@@ -532,7 +539,7 @@ void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* r
             OrcStats st; memset(&st, 0, sizeof st);
             float px[4];
             f3 d = f3_make(rays[3 * idx], rays[3 * idx + 1], rays[3 * idx + 2]);
-            trace_pixel(s, args, d, lightY, lightZ, px, &st, 0);
+            trace_pixel(s, args, d, lightY, lightZ, px, &st, extensions);
             innerOut[idx] = (uint32_t)st.innerVisits;
             triOut[idx] = (uint32_t)st.triTests;
         }

@@ -116,6 +116,7 @@ void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, i
  * surface and carrying (1 - opacity) of the energy; no shadow ray is traced for such a hit (its factor is not used). */
 #define ORC_EXT_SHADOWS 1
 #define ORC_EXT_REFRACTION 2
+#define ORC_EXT_PRIMARY_ONLY 4      /* analysis only: stop after the first bounce (per-pixel cost split, orc_trace_costs_ex) */
 void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                   int row0, int row1, float* out, OrcStats* stats, int nthreads, int extensions);
 void orc_postprocess(float* rgba, int width, int height, int row0, int row1);
@@ -126,6 +127,8 @@ void orc_pack_unorm8(const float* rgba, uint8_t* out, int width, int height, int
 /* Analysis helper: per-pixel inner visits / triangle tests (both bounces) of a full frame. */
 void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                      uint32_t* innerOut, uint32_t* triOut, int nthreads);
+void orc_trace_costs_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
+                        uint32_t* innerOut, uint32_t* triOut, int nthreads, int extensions);
 /* Analysis hook: count child-pair fetches per left-child index (NULL disables). */
 void orc_set_visit_counts(uint32_t* counts);
 /* Closest-hit query for arbitrary world-space rays: the instance loop of kernel_main.cl:198-217. */
