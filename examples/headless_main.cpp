@@ -5,8 +5,12 @@
 //   crt_headless <skybox.ppm> <out.ppm> <width> <height> <frames> <camx> <camy> <camz> <frontx> <fronty> <frontz> <mesh.obj>...
 //
 // Every mesh is registered once with the identity transform and its own materials (ResourceManager::DefaultMaterial).
+// Textures may be JPEG (as upstream's) or binary PPM. Environment: CRT_ASSET_ROOT = the folder that holds `Assets/` (where the
+// texture paths inside upstream's .mtl/.clm files resolve, ResourceManager::SetAssetRoot); CRT_DEVICES = "0,1,2,3" renders
+// on several GPUs from this one process (Renderer::InitializeDevices) -- the rest of the program does not change.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "../clraytracer_amd/host/Renderer.hpp"
 
@@ -18,7 +22,12 @@ int main(int argc, char** argv)
     const Vector3f camPos((float)std::atof(argv[6]), (float)std::atof(argv[7]), (float)std::atof(argv[8]));
     const Vector3f camFront((float)std::atof(argv[9]), (float)std::atof(argv[10]), (float)std::atof(argv[11]));
 
-    if (!Renderer::Initialize(/*device*/0, width, height)) { std::fprintf(stderr, "Renderer::Initialize failed (%d)\n", Renderer::LastError()); return 1; }
+    std::vector<int> devices;
+    if (const char* list = std::getenv("CRT_DEVICES")) for (const char* p = list; *p;) { devices.push_back(std::atoi(p)); p = std::strchr(p, ','); if (!p) break; ++p; }
+    const int ok = devices.size() > 1 ? Renderer::InitializeDevices(devices.data(), (int)devices.size(), width, height)
+                                      : Renderer::Initialize(devices.empty() ? 0 : devices[0], width, height);
+    if (!ok) { std::fprintf(stderr, "Renderer::Initialize failed (%d)\n", Renderer::LastError()); return 1; }
+    if (const char* root = std::getenv("CRT_ASSET_ROOT")) ResourceManager::SetAssetRoot(root);
 
     // Engine_Start (Engine.cpp:56-80)
     ResourceManager::PrepareMeshes();
