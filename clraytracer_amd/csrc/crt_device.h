@@ -136,6 +136,8 @@ struct CrtFrame {
     int listCap;              // capacity of one XCD's list = slotsPerXcd + 3 * CRT_MAX_SPLIT
     uint32_t* cost;           // per tile: shader cycles the wave spent on it this frame (feeds the next frame's order)
     uint32_t smallPacket;     // packets with at most this many working lanes run every step kind per trip (closest_hit)
+    uint32_t suspendAt;       // straggler hand-off (crt_trace_fast_kernel): suspend the remaining lanes once this few still work; 0 = never
+    uint32_t suspendAfter;    // ... and only in waves that have run at least this many trips in the current bounce
 };
 
 struct v3 { float x, y, z; };
@@ -445,6 +447,9 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
 
 // Packets with at most this many lanes still working advance every lane through every step kind each trip
 // (latency of the longest ray matters, issue slots do not); larger packets vote for one step kind per trip.
+#ifndef CRT_SUSPEND_AT
+#define CRT_SUSPEND_AT 0             // straggler hand-off (opt-in, CRT_SUSPEND_AT=8): the last lanes of a wave leave for crt_straggler_kernel when this few still work
+#endif
 #ifndef CRT_SMALL_PACKET
 #define CRT_SMALL_PACKET 16          // synchronous frames (and queries): the slowest wave decides
 #endif
@@ -709,4 +714,117 @@ __device__ __forceinline__ int shade_bounce(const CrtDevScene& S, const Closest&
     if (DEFER_ENERGY) *ndlOut = ndl;
     else ps.energy = ps.energy * specular_x(ndl, 1.0f);      // shadow = 1.0f (kernel_main.cl:258: no shadow ray upstream)
     return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Straggler hand-off (round 2): resumable closest-hit walk + the record a suspended ray travels in.
+//
+// The rays of one 8x8 tile need very different numbers of steps (wave duration p50 18 us, p90 288 us on multi-1M), and a
+// wave-trip costs the same VALU issue slots whether 60 lanes or 2 take part: on multi-1M a third of all wave-trips run
+// with <= 8 working lanes and hold 3 % of the lane-steps (oracle per-pixel costs). So when the
+// working lanes of a wave drop to `suspendAt`, those lanes write their complete state -- path, running best hit,
+// traversal position, remaining candidate instances, traversal stack -- to a queue and leave; the rest of the wave goes on
+// to shading and the next bounce at once. A second kernel (crt_straggler_kernel) picks the suspended rays up 64 at a
+// time and finishes them: dense packets of long rays instead of mostly empty waves. Every ray still performs exactly
+// upstream's sequence of instance entries, node visits and triangle tests; only WHICH wave performs the tail changes.
+// Used by the plain launch (no counters, stamps, shadow rays; <= 64 instances); everything else keeps closest_hit.
+// ------------------------------------------------------------------------------------------------
+struct CrtSuspended {                 // 256 B per suspended ray
+    uint32_t pixel;                   // py * width + px
+    uint32_t state;                   // bounce | anyHit << 1 | active << 2 | inters << 3 | sp << 8 (9 bits) | prot << 20 (9 bits)
+    uint32_t curInst, ref;
+    float o[3], d[3], result[3], energy;
+    float cDistance; int32_t cInstance; float cT, cU, cV; uint32_t cTri;
+    float mo[3], md[3];
+    float tT, tU, tV; uint32_t tTri;
+    uint32_t candLo, candHi;
+    uint32_t stack[CRT_STACK_DEPTH];
+};
+static_assert(sizeof(CrtSuspended) == 256, "CrtSuspended is 64 dwords");
+
+struct RayWalk { Traversal<false> T; Closest c; unsigned long long cand; };
+
+__device__ __forceinline__ void walk_begin(const CrtDevScene& S, v3 o, v3 d, RayWalk& W)
+{
+    LaneCounters lc;
+    W.c.distance = 99999.0f; W.c.hitInstance = 0; W.c.anyHit = 0;
+    W.c.hit.t = 0.0f; W.c.hit.u = 0.0f; W.c.hit.v = 0.0f; W.c.hit.tri = 0;
+    W.T.reset();
+    W.cand = candidate_mask<false>(S, o, d, 0u, S.numInstances, lc);       // <= 64 instances: one chunk
+}
+__device__ __forceinline__ void walk_idle(RayWalk& W) { W.T.reset(); W.cand = 0; W.c.distance = 99999.0f; W.c.hitInstance = 0; W.c.anyHit = 0; W.c.hit.t = 0.f; W.c.hit.u = 0.f; W.c.hit.v = 0.f; W.c.hit.tri = 0; }
+
+// Advances every lane's walk; returns when no lane has work left (false) or -- SUSPEND -- when at most `suspendAt` lanes
+// still have (true for exactly those lanes: the caller suspends them). The loop body is closest_hit's.
+template <bool SUSPEND>
+__device__ __forceinline__ bool walk_run(const CrtDevScene& S, v3 o, v3 d, const CrtStack& stack, RayWalk& W, uint32_t smallPacket, uint32_t suspendAt,
+                                         uint32_t suspendAfter = 0)
+{
+    LaneCounters lc;
+    Traversal<false>& T = W.T;
+    uint32_t trips = 0;
+    for (;; ++trips) {
+        const bool wEnter = !T.active && W.cand != 0;
+        const bool wInner = T.at_inner();
+        const bool wLeaf = T.at_leaf();
+        const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
+        const uint32_t n = nE + nI + nL;
+        if (n == 0) return false;
+        // only waves that have already run `suspendAfter` trips hand their last lanes off: rays that are still going then
+        // are the long ones (the distribution is heavy-tailed); the short tails of ordinary tiles are not worth 256 B of state
+        if (SUSPEND) { if (n <= suspendAt && trips >= suspendAfter) return wEnter || wInner || wLeaf; }
+        const bool all = n <= smallPacket;
+        const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
+        if (all || (!runI && !runL)) {
+            if (wEnter) {
+                const uint32_t k = (uint32_t)__ffsll((long long)W.cand) - 1u;
+                W.cand &= W.cand - 1;
+                T.enter(S, k, o, d, W.c.distance, lc);
+            }
+        }
+        if (all || runI) { if (T.at_inner()) T.inner(S, stack, W.c, lc); }
+        if (all || runL) { if (T.at_leaf()) T.template leaf<false>(S, stack, W.c, lc); }
+    }
+}
+
+__device__ __forceinline__ void suspend_store(CrtSuspended* __restrict__ r, uint32_t pixel, int bounce, const PathState& ps, const RayWalk& W, const CrtStack& stack)
+{
+    const Traversal<false>& T = W.T;
+    uint4* q = reinterpret_cast<uint4*>(r);
+    const uint32_t sp = (uint32_t)T.sp > 511u ? 511u : (uint32_t)T.sp;
+    const uint32_t state = (uint32_t)bounce | ((uint32_t)(W.c.anyHit != 0) << 1) | ((uint32_t)T.active << 2) | ((uint32_t)(T.inters != 0) << 3) | (sp << 8) | ((uint32_t)T.prot << 20);
+    q[0] = make_uint4(pixel, state, T.curInst, T.ref);
+    q[1] = make_uint4(__float_as_uint(ps.o.x), __float_as_uint(ps.o.y), __float_as_uint(ps.o.z), __float_as_uint(ps.d.x));
+    q[2] = make_uint4(__float_as_uint(ps.d.y), __float_as_uint(ps.d.z), __float_as_uint(ps.result.x), __float_as_uint(ps.result.y));
+    q[3] = make_uint4(__float_as_uint(ps.result.z), __float_as_uint(ps.energy), __float_as_uint(W.c.distance), (uint32_t)W.c.hitInstance);
+    q[4] = make_uint4(__float_as_uint(W.c.hit.t), __float_as_uint(W.c.hit.u), __float_as_uint(W.c.hit.v), W.c.hit.tri);
+    q[5] = make_uint4(__float_as_uint(T.mo.x), __float_as_uint(T.mo.y), __float_as_uint(T.mo.z), __float_as_uint(T.md.x));
+    q[6] = make_uint4(__float_as_uint(T.md.y), __float_as_uint(T.md.z), __float_as_uint(T.tr.t), __float_as_uint(T.tr.u));
+    q[7] = make_uint4(__float_as_uint(T.tr.v), T.tr.tri, (uint32_t)W.cand, (uint32_t)(W.cand >> 32));
+    const uint32_t live = T.sp > CRT_STACK_DEPTH ? (uint32_t)CRT_STACK_DEPTH : (uint32_t)(T.sp < 0 ? 0 : T.sp);   // slots that hold pending entries
+    for (uint32_t s = 0; s < live; ++s) r->stack[s] = stack.read((int)s);
+}
+
+__device__ __forceinline__ void suspend_load(const CrtSuspended* __restrict__ r, uint32_t& pixel, int& bounce, PathState& ps, RayWalk& W, const CrtStack& stack)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(r);
+    const uint4 a = q[0], b = q[1], c2 = q[2], d2 = q[3], e = q[4], f = q[5], g2 = q[6], h = q[7];
+    Traversal<false>& T = W.T;
+    pixel = a.x; bounce = (int)(a.y & 1u);
+    W.c.anyHit = (int)((a.y >> 1) & 1u); T.active = ((a.y >> 2) & 1u) != 0; T.inters = (int)((a.y >> 3) & 1u);
+    T.sp = (int)((a.y >> 8) & 0x1FFu); T.prot = (int)((a.y >> 20) & 0x1FFu);
+    T.curInst = a.z; T.ref = a.w;
+    ps.o = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+    ps.d = mk3(__uint_as_float(b.w), __uint_as_float(c2.x), __uint_as_float(c2.y));
+    ps.result = mk3(__uint_as_float(c2.z), __uint_as_float(c2.w), __uint_as_float(d2.x));
+    ps.energy = __uint_as_float(d2.y);
+    W.c.distance = __uint_as_float(d2.z); W.c.hitInstance = (int)d2.w;
+    W.c.hit.t = __uint_as_float(e.x); W.c.hit.u = __uint_as_float(e.y); W.c.hit.v = __uint_as_float(e.z); W.c.hit.tri = e.w;
+    T.mo = mk3(__uint_as_float(f.x), __uint_as_float(f.y), __uint_as_float(f.z));
+    T.md = mk3(__uint_as_float(f.w), __uint_as_float(g2.x), __uint_as_float(g2.y));
+    T.inv = mk3(1.0f / T.md.x, 1.0f / T.md.y, 1.0f / T.md.z);        // as Traversal::enter computes it
+    T.tr.t = __uint_as_float(g2.z); T.tr.u = __uint_as_float(g2.w); T.tr.v = __uint_as_float(h.x); T.tr.tri = h.y;
+    W.cand = (unsigned long long)h.z | ((unsigned long long)h.w << 32);
+    const uint32_t live = T.sp > CRT_STACK_DEPTH ? (uint32_t)CRT_STACK_DEPTH : (uint32_t)T.sp;
+    for (uint32_t s = 0; s < live; ++s) stack.write((int)s, r->stack[s]);
 }

@@ -237,6 +237,106 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
     }
 }
 
+// ---- Trace with straggler hand-off (the plain launch: no counters / stamps / shadow rays, <= 64 instances) ----------
+// Same per-pixel work as crt_trace_kernel; when at most F.suspendAt lanes of the wave still have traversal work, those
+// lanes are suspended into `queue` (crt_device.h, CrtSuspended) and finished by crt_straggler_kernel in dense packets.
+struct CrtSuspendQueue { CrtSuspended* records; uint32_t* count; uint32_t* head; uint32_t capacity; };
+
+template <bool REFRACT>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD)
+void crt_trace_fast_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, CrtSuspendQueue Q)
+{
+    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
+    int px, py, costSlot = -1;
+    bool isQuadrant = false;
+    const unsigned long long tc0 = F.cost ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool active = lane_pixel(F, px, py, &costSlot, &isQuadrant);
+    PathState ps;
+    ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
+    ps.d = active ? raygen_dir(F, px, py) : mk3(0.0f, 0.0f, 1.0f);
+    ps.result = mk3(0.0f, 0.0f, 0.0f);
+    ps.energy = 1.0f;
+    bool alive = active;                       // this lane still owns its pixel (not finished, not suspended)
+    bool suspended = false;
+    for (int bounce = 0; bounce < 2; ++bounce) {
+        RayWalk W;
+        if (alive) walk_begin(S, ps.o, ps.d, W); else walk_idle(W);
+        const bool unfinished = walk_run<true>(S, ps.o, ps.d, stack, W, F.smallPacket, F.suspendAt, F.suspendAfter);
+        const unsigned long long m = __ballot(unfinished);
+        if (m != 0) {                          // wave-uniform: the working lanes leave together
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(Q.count, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (unfinished) {
+                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+                int b2 = blockIdx.x, lane2 = (int)(threadIdx.x & 63);
+                asm volatile("" : "+s"(b2), "+v"(lane2));
+                int qx, qy;
+                (void)lane_pixel(F, qx, qy, nullptr, nullptr, b2, lane2);
+                suspend_store(Q.records + (size_t)(base + rank), (uint32_t)qy * (uint32_t)F.width + (uint32_t)qx, bounce, ps, W, stack);
+                alive = false; suspended = true;
+            }
+        }
+        if (alive) {
+            float ndl = 0.0f;
+            const int cont = shade_bounce<false, REFRACT>(S, W.c, ps, bounce, F.lightY, F.lightZ, &ndl);
+            if (!cont) alive = false;          // finished: the pixel is written below
+        }
+        if (__ballot(alive) == 0) break;
+    }
+    if (active && !suspended) {
+        int b2 = blockIdx.x, lane2 = (int)(threadIdx.x & 63);
+        asm volatile("" : "+s"(b2), "+v"(lane2));
+        int qx, qy;
+        (void)lane_pixel(F, qx, qy, nullptr, nullptr, b2, lane2);
+        out[(size_t)qy * (size_t)F.width + (size_t)qx] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+    if (F.cost && costSlot >= 0) {
+        unsigned long long dt = __builtin_amdgcn_s_memtime() - tc0;
+        if (isQuadrant) dt >>= 1;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&F.cost[costSlot], dt > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)dt);
+    }
+}
+
+// Finishes the suspended rays: resident waves pull packets of 64 records (one atomic per packet) until the queue is empty.
+// A ray suspended during its first bounce also gets its second one here (traced to completion: no second hand-off).
+template <bool REFRACT>
+__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD_COUNT)      // few, long-lived waves: registers matter here, occupancy does not
+void crt_straggler_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, CrtSuspendQueue Q)
+{
+    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
+    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
+    uint32_t total = *Q.count;
+    total = total < Q.capacity ? total : Q.capacity;
+    for (;;) {
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(Q.head, (uint32_t)CRT_BLOCK);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= total) break;
+        const uint32_t k = base + (threadIdx.x & 63);
+        const bool valid = k < total;
+        PathState ps; ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.result = ps.o; ps.energy = 1.0f;
+        RayWalk W; walk_idle(W);
+        uint32_t pixel = 0; int bounce = 0;
+        if (valid) suspend_load(Q.records + (size_t)k, pixel, bounce, ps, W, stack);
+        (void)walk_run<false>(S, ps.o, ps.d, stack, W, 64u, 0u);     // rays from everywhere: every lane steps every trip
+        bool again = false;
+        if (valid) {
+            float ndl = 0.0f;
+            const int cont = shade_bounce<false, REFRACT>(S, W.c, ps, bounce, F.lightY, F.lightZ, &ndl);
+            again = cont != 0 && bounce == 0;
+        }
+        if (__ballot(again) != 0) {            // second bounce of the rays that were suspended during their first
+            if (again) walk_begin(S, ps.o, ps.d, W); else walk_idle(W);
+            (void)walk_run<false>(S, ps.o, ps.d, stack, W, 64u, 0u);     // rays from everywhere: every lane steps every trip
+            if (again) { float ndl = 0.0f; (void)shade_bounce<false, REFRACT>(S, W.c, ps, 1, F.lightY, F.lightZ, &ndl); }
+        }
+        if (valid) out[pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+    }
+}
+
 // ---- wavefront form of Trace: one launch per bounce with ballot compaction in between ----------------
 // The megakernel above runs bounce 1 inside the same wave as bounce 0, at the lane density of the pixels
 // that hit something (31 % on multi-1M) and on top of the wave's bounce-0 latency. Here bounce 0 writes the
