@@ -29,3 +29,29 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
         got2 = s.read_output()
     assert np.array_equal(bits(got), bits(ref)) and np.array_equal(bits(got2), bits(ref))
     assert cnt == ref_cnt
+
+
+@pytest.mark.parametrize("name", ["tiny", "multi-1M", "sponza-sibenik"])
+def test_straggler_hand_off_is_bit_identical(name, monkeypatch):
+    """CRT_SUSPEND_AT=8 (opt-in, crt_trace_fast_kernel + crt_straggler_kernel): the last working lanes of a wave are
+    suspended -- path, running hit, traversal position, candidate instances, stack -- and finished in dense packets by a
+    second kernel. Same pixels as the committed full-size answers (synchronous, pipelined, with refraction)."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_frames.json")))[name]
+    sc = scenes.get(name)
+    monkeypatch.setenv("CRT_SUSPEND_AT", "8")
+    monkeypatch.setenv("CRT_SUSPEND_AFTER", "16")
+    with driver.Session(gold["width"], gold["height"], device=0) as s:
+        s.load_scene(sc)
+        for flags in (0, 0, 4, 4, 4, 4):
+            s.render_raw(flags)
+        assert hashlib.sha256(np.ascontiguousarray(s.read_output()).tobytes()).hexdigest() == gold["frame_sha256"]
+        s.render_raw(256)
+        with_refraction = s.read_output()
+    monkeypatch.delenv("CRT_SUSPEND_AT")
+    with driver.Session(gold["width"], gold["height"], device=0) as s:
+        s.load_scene(sc)
+        s.render_raw(256)
+        assert np.array_equal(bits(s.read_output()), bits(with_refraction))
