@@ -467,7 +467,8 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
 // ANYHIT (shadow rays, CRT_RENDER_SHADOWS): a lane stops at the first triangle that passes -- inside the leaf, and
 // for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
 // first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
-template <bool COUNT, bool ITERS = false, bool ANYHIT = false, bool TLAS = false>
+// ALLSTEPS (frames in flight): no vote at all, see the loop.
+template <bool COUNT, bool ITERS = false, bool ANYHIT = false, bool TLAS = false, bool ALLSTEPS = false>
 __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, const CrtStack& stack, LaneCounters& lc, uint32_t smallPacket)
 {
     Closest c;
@@ -524,11 +525,17 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
             const bool wEnter = !done && !T.active;
             const bool wInner = !done && T.at_inner();
             const bool wLeaf = !done && T.at_leaf();
-            const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
-            if (nE + nI + nL == 0) break;
+            bool all, runI = false, runL = false;
+            if (ALLSTEPS) {                                        // every packet runs every step kind: one ballot decides when the wave is done
+                if (__ballot(wEnter || wInner || wLeaf) == 0) break;
+                all = true;
+            } else {
+                const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
+                if (nE + nI + nL == 0) break;
+                all = (nE + nI + nL) <= smallPacket;
+                runI = nI > 0 && nI >= nE && nI >= nL; runL = !runI && nL > 0 && nL >= nE;
+            }
             if (ITERS) { if (first_active_lane()) lc.pops++; }
-            const bool all = (nE + nI + nL) <= smallPacket;
-            const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
             if (all || (!runI && !runL)) {
                 if (wEnter) {
                     if (ANYHIT && c.anyHit) done = true;           // occluded: later instances are never visited

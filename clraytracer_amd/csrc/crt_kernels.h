@@ -171,7 +171,9 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
 // product is 0 whatever the shadow factor).
 // TLAS: candidates come from the instance tree instead of the linear sphere loop (scenes with many instances).
 // REFRACT (CRT_RENDER_REFRACTION, the other README TODO of upstream, oracle-defined): translucent materials transmit.
-template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false, bool REFRACT = false>
+// ALLSTEPS: every packet runs every step kind per trip (what frames in flight use: smallPacket = 64), compiled without the
+// vote -- one ballot per trip instead of three ballots, three popcounts and the majority logic (+3 %).
+template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false, bool REFRACT = false, bool ALLSTEPS = false>
 __global__ __launch_bounds__(CRT_BLOCK, (COUNT || STAMP) ? CRT_WAVES_PER_SIMD_COUNT : CRT_WAVES_PER_SIMD)
 void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
@@ -192,7 +194,7 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
         ps.energy = 1.0f;
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT, STAMP, false, TLAS>(S, ps.o, ps.d, stack, lc, F.smallPacket);
+            Closest c = closest_hit<COUNT, STAMP, false, TLAS, ALLSTEPS>(S, ps.o, ps.d, stack, lc, F.smallPacket);
             float ndl = 0.0f;
             const int cont = shade_bounce<SHADOW, REFRACT>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
@@ -201,7 +203,7 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
                 float shadow = 1.0f;
                 if (bounce == 0 && ndl > 0.0f) {
                     if (COUNT) { lc.rays++; lc.shadowRays++; }
-                    const Closest sc = closest_hit<COUNT, false, true, TLAS>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc, F.smallPacket);
+                    const Closest sc = closest_hit<COUNT, false, true, TLAS, ALLSTEPS>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc, F.smallPacket);
                     if (sc.anyHit) { shadow = 0.0f; if (COUNT) lc.shadowHits++; }
                 }
                 ps.energy = ps.energy * specular_x(ndl, shadow);

@@ -958,13 +958,16 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, refract = (flags & CRT_RENDER_REFRACTION) != 0;
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
         const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
-#define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) crt_trace_kernel<C_, false, S_, T_, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
-                                           else crt_trace_kernel<C_, false, S_, T_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
+        const bool allSteps = !count && F.smallPacket >= (uint32_t)CRT_BLOCK;      // frames in flight: the instantiation without the vote
+#define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) do { if (allSteps) crt_trace_kernel<C_, false, S_, T_, R_, !C_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
+                                               else crt_trace_kernel<C_, false, S_, T_, R_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
+#define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) CRT_LAUNCH_TRACE3(C_, S_, T_, true); else CRT_LAUNCH_TRACE3(C_, S_, T_, false); } while (0)
 #define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) CRT_LAUNCH_TRACE2(C_, S_, true); else CRT_LAUNCH_TRACE2(C_, S_, false); } while (0)
         if (count) { if (shadow) CRT_LAUNCH_TRACE(true, true); else CRT_LAUNCH_TRACE(true, false); }
         else       { if (shadow) CRT_LAUNCH_TRACE(false, true); else CRT_LAUNCH_TRACE(false, false); }
 #undef CRT_LAUNCH_TRACE
 #undef CRT_LAUNCH_TRACE2
+#undef CRT_LAUNCH_TRACE3
     }
     HIPCHK(hipGetLastError());
     return CRT_OK;
