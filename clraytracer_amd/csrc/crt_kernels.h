@@ -492,7 +492,7 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD_COUNT) void crt_query
         v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
         v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
         lc.rays++;
-        Closest c = closest_hit<true, false, false, TLAS>(S, o, d, stack, lc, (uint32_t)CRT_SMALL_PACKET);
+        Closest c = closest_hit<true, false, false, TLAS>(S, o, d, stack, lc, 16u);
         CrtRayHit h;
         if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
         else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }
