@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false, false, false, false>"   # <COUNT, STAMP, SHADOW, TLAS>: the kernel of the timed region
+    kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false, false, false, false, false, true>"   # <COUNT, STAMP, SHADOW, TLAS, REFRACT, ALLSTEPS>: the kernel of the timed region
     base = os.path.join(ROOT, "gpurun_out")
     out = {"tag": tag, "kernel": kern, "kernel_stats": [], "counters": {}, "bench_line": None}
     def newest(pattern):
