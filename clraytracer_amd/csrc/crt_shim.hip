@@ -20,6 +20,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <functional>
+#include <atomic>
 
 // ------------------------------------------------------------------------------------------------
 // host state
@@ -1306,31 +1307,59 @@ int crt_row_owner(int row, int bandRows, int nRanks)
 // devices; the calling thread submits the primary's share last (its stream must wait on events the others have recorded).
 // ------------------------------------------------------------------------------------------------
 struct Worker {
+    // Job hand-over by generation counters: the owner bumps `posted`, the worker bumps `finished`. Both sides spin briefly
+    // (a frame's share is submitted in ~30 us, a condition-variable wake-up alone costs 5-10 us each way) and fall back
+    // to the condition variable, so an idle session does not burn a core.
     std::thread th; std::mutex m; std::condition_variable cv;
-    std::function<int()> job; bool hasJob = false, quit = false, done = true; int result = 0;
+    std::function<int()> job; std::atomic<unsigned> posted{0}, finished{0}; std::atomic<bool> quit{false}; int result = 0;
     State* st = nullptr; int device = 0;
+    static constexpr int kSpins = 4000;
     void start(State* s, int dev)
     {
         st = s; device = dev;
         th = std::thread([this] {
             (void)hipSetDevice(device);
             G = st;
-            std::unique_lock<std::mutex> lk(m);
+            unsigned seen = 0;
             for (;;) {
-                cv.wait(lk, [this] { return hasJob || quit; });
-                if (quit) return;
-                std::function<int()> f = std::move(job); hasJob = false;
-                lk.unlock();
-                const int r = f();
-                lk.lock();
-                result = r; done = true;
+                int spins = 0;
+                while (posted.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_acquire)) {
+                    if (++spins < kSpins) { __builtin_ia32_pause(); continue; }
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire); });
+                }
+                if (quit.load(std::memory_order_acquire)) return;
+                seen = posted.load(std::memory_order_acquire);
+                result = job();
+                finished.store(seen, std::memory_order_release);
+                { std::lock_guard<std::mutex> lk(m); }
                 cv.notify_all();
             }
         });
     }
-    void post(std::function<int()> f) { std::lock_guard<std::mutex> lk(m); job = std::move(f); hasJob = true; done = false; cv.notify_all(); }
-    int wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return done; }); return result; }
-    void stop() { { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); } if (th.joinable()) th.join(); }
+    void post(std::function<int()> f)
+    {
+        job = std::move(f);
+        { std::lock_guard<std::mutex> lk(m); posted.fetch_add(1, std::memory_order_release); }
+        cv.notify_all();
+    }
+    int wait()
+    {
+        const unsigned want = posted.load(std::memory_order_acquire);
+        int spins = 0;
+        while (finished.load(std::memory_order_acquire) != want) {
+            if (++spins < kSpins) { __builtin_ia32_pause(); continue; }
+            std::unique_lock<std::mutex> lk(m);
+            cv.wait(lk, [&] { return finished.load(std::memory_order_acquire) == want; });
+        }
+        return result;
+    }
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit.store(true, std::memory_order_release); }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
 };
 
 struct Group {
