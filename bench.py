@@ -7,7 +7,9 @@
 One *step* = one frame through the hot path: crt_render (RayGen fused into Trace, both bounces) on a
 scene that is already resident in HBM. By default three frames are in flight (CRT_RENDER_ASYNC: frames
 k+1, k+2 are submitted while frame k runs, each on its own HIP stream and output buffer, so the long-ray
-tail of one frame is hidden behind the next); all K frames are complete before the clock stops.
+tail of one frame is hidden behind the next; with N >= 4 ranks eight, because a rank's share of the
+frame shrinks and its slowest tile does not); all K frames are complete before the
+clock stops.
 `--frames-in-flight 1` gives the reference's Render()+clFinish per frame (Renderer.cpp:305-367).
 Workload:
   N == 1 : BASELINE config 4 -- `multi-1M` (8 meshes, 1,000,960 triangles, 16 instances, textures),
@@ -154,7 +156,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--band-rows", type=int, default=16)
-    ap.add_argument("--frames-in-flight", type=int, default=3, help="1 = synchronous frames (Render()+clFinish), 2..4 = pipelined")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="1 = synchronous frames (Render()+clFinish), 2..8 = pipelined; default 3, or 8 when a rank renders 1/4 of the frame or less (N >= 4)")
     ap.add_argument("--shadows", action="store_true", help="extension: one any-hit shadow ray per lit first hit (CRT_RENDER_SHADOWS); not the reference's semantics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -176,8 +179,14 @@ def main():
     if world != n and not inproc:
         n = world
 
-    flight = max(1, min(4, args.frames_in_flight))
+    # A rank's share of the frame shrinks with N but its slowest tiles do not: a frame on a slot lasts at least as long as its
+    # slowest wave (0.3-0.5 ms on multi-1M), so the frames a slot can deliver per second are capped and a small share needs
+    # more slots to keep the GPU full. One GPU: 3 vs 4 vs 6 slots measure the same.
+    flight = args.frames_in_flight if args.frames_in_flight > 0 else (3 if n < 4 else 8)
+    flight = max(1, min(8, flight))
     os.environ["CRT_FRAMES_IN_FLIGHT"] = str(flight)   # read by crt_init
+    if flight > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per slot's stream; read by the HIP runtime at its first call
 
     import ctypes as C
     import numpy as np

@@ -27,7 +27,7 @@
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-#define CRT_MAX_FRAMES_IN_FLIGHT 4
+#define CRT_MAX_FRAMES_IN_FLIGHT 8
 #define CRT_MAX_DEVICES 16
 
 struct EventSet {
@@ -69,7 +69,7 @@ struct State {
     FrameSlot slot[CRT_MAX_FRAMES_IN_FLIGHT]; int nSlots = 3;
     hipStream_t stream = nullptr;              // == slot[0].stream: uploads, queries, diagnostics
     int cur = 0;                               // slot of the most recently submitted frame
-    int readbackRing[CRT_MAX_FRAMES_IN_FLIGHT] = { -1, -1, -1, -1 }; unsigned readbackCount = 0;   // slots of the latest CRT_RENDER_READBACK frames
+    int readbackRing[CRT_MAX_FRAMES_IN_FLIGHT] = { -1, -1, -1, -1, -1, -1, -1, -1 }; unsigned readbackCount = 0;   // slots of the latest CRT_RENDER_READBACK frames
     unsigned asyncSeq = 0; bool othersBusy = false;   // frames possibly running on slots > 0
     int width = 0, height = 0;
     int bandRows = 16, rank = 0, nRanks = 1;
@@ -122,7 +122,7 @@ thread_local State* G = nullptr;
 int quiesce()
 {
     if (g.othersBusy) {
-        for (int i = 1; i < CRT_MAX_FRAMES_IN_FLIGHT; ++i) HIPCHK(hipStreamSynchronize(g.slot[i].stream));
+        for (int i = 1; i < g.nSlots; ++i) HIPCHK(hipStreamSynchronize(g.slot[i].stream));
         g.othersBusy = false;
     }
     return CRT_OK;
@@ -203,10 +203,10 @@ int ensure_suspend_queue(FrameSlot& fs, size_t records)
 int alloc_frame_buffers(int w, int h)
 {
     const size_t pixels = (size_t)w * (size_t)h;
-    float* rays = nullptr; CrtBounceRay* queue = nullptr; float4* outs[CRT_MAX_FRAMES_IN_FLIGHT] = { nullptr, nullptr, nullptr, nullptr };
+    float* rays = nullptr; CrtBounceRay* queue = nullptr; float4* outs[CRT_MAX_FRAMES_IN_FLIGHT] = {};
     hipError_t e = hipMalloc(&queue, sizeof(CrtBounceRay) * pixels);
     if (e == hipSuccess) e = hipMalloc(&rays, sizeof(float) * 3 * pixels);
-    for (int i = 0; i < CRT_MAX_FRAMES_IN_FLIGHT && e == hipSuccess; ++i) {
+    for (int i = 0; i < g.nSlots && e == hipSuccess; ++i) {   // slots past nSlots are never rendered into
         e = hipMalloc(&outs[i], sizeof(float4) * pixels);
         if (e == hipSuccess) e = hipMemsetAsync(outs[i], 0, sizeof(float4) * pixels, g.stream);
     }
@@ -457,7 +457,8 @@ int collect_set(EventSet& es)
 
 int collect_timing()
 {
-    for (FrameSlot& fs : g.slot) {
+    for (int i = 0; i < g.nSlots; ++i) {
+        FrameSlot& fs = g.slot[i];
         const int older = fs.es[0].seq <= fs.es[1].seq ? 0 : 1;
         RCCHK(collect_set(fs.es[older]));
         RCCHK(collect_set(fs.es[older ^ 1]));
@@ -490,7 +491,12 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipGetDeviceProperties(&prop, device));
     snprintf(g.deviceName, sizeof g.deviceName, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     g.device = device;
-    for (FrameSlot& fs : g.slot) {
+    // frames in flight: 3 by default; more pays when a frame is small against its slowest tile (a rank's 1/8 share of a
+    // frame: DESIGN.md 6). Each slot has its own stream; past four the runtime needs GPU_MAX_HW_QUEUES raised before
+    // its first call, or it folds the streams onto four hardware queues (crt_init_devices does that when it still can).
+    { const char* e = getenv("CRT_FRAMES_IN_FLIGHT"); g.nSlots = e ? atoi(e) : 3; if (g.nSlots < 1) g.nSlots = 1; if (g.nSlots > CRT_MAX_FRAMES_IN_FLIGHT) g.nSlots = CRT_MAX_FRAMES_IN_FLIGHT; }
+    for (int si = 0; si < g.nSlots; ++si) {
+        FrameSlot& fs = g.slot[si];
         HIPCHK(hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
         for (EventSet& es : fs.es) for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&es.ev[i]));
         HIPCHK(hipMalloc(&fs.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
@@ -507,7 +513,6 @@ static int init_impl(int device, int width, int height)
     }
     HIPCHK(hipEventCreate(&g.statStart));
     g.stream = g.slot[0].stream; g.cur = 0; g.asyncSeq = 0; g.othersBusy = false;
-    { const char* e = getenv("CRT_FRAMES_IN_FLIGHT"); g.nSlots = e ? atoi(e) : 3; if (g.nSlots < 1) g.nSlots = 1; if (g.nSlots > CRT_MAX_FRAMES_IN_FLIGHT) g.nSlots = CRT_MAX_FRAMES_IN_FLIGHT; }
 
     g.triCap = (size_t)CRT_MAX_TRIANGLES * 2;           // ResourceManager.cpp:158
     g.nodeCap = (size_t)CRT_MAX_TRIANGLES * 2;          // ResourceManager.cpp:159 (MAX_BVHMEMORY * 2)
@@ -1406,6 +1411,7 @@ int crt_init_devices(const int* devices, int numDevices, int width, int height)
 {
     if (M.n != 0) return CRT_E_BAD_ARGUMENT;
     if (!devices || numDevices < 1 || numDevices > CRT_MAX_DEVICES) return CRT_E_BAD_ARGUMENT;
+    { const char* e = getenv("CRT_FRAMES_IN_FLIGHT"); if (e && atoi(e) > 4) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }   // read by the HIP runtime at its first call
     int rc = CRT_OK;
     M.n = numDevices;
     for (int d = 0; d < numDevices && rc == CRT_OK; ++d) {
