@@ -131,6 +131,7 @@ HOST_API = {
     "crth_set_postprocess": (None, [C.c_int]),
     "crth_set_shadows": (None, [C.c_int]),
     "crth_set_refraction": (None, [C.c_int]),
+    "crth_set_fxaa": (None, [C.c_int]),
     "crth_set_unorm8": (None, [C.c_int]),
     "crth_map_output_rgba8": (_vp, []),
     "crth_set_pipelined": (None, [C.c_int]),

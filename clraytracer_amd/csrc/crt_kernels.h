@@ -453,6 +453,62 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_postprocess_kernel(CrtFrame F, 
     img[idx] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
 }
 
+// FXAA (kernel_main.cl:289-340) -- EXTENSION (CRT_RENDER_FXAA): upstream's function is dead code (call commented out at
+// kernel_main.cl:349, no return, in-place neighbour reads); the semantics are the oracle's (orc_fxaa): result = the rgb it
+// assigns last, neighbours from the unmodified frame `src`, reads clamped to the edge, uv = p / resolution, linear taps as
+// OpenCL 1.2 8.2 defines CLK_FILTER_LINEAR. Same operations in the same order as the oracle: bit-identical.
+__device__ __forceinline__ v3 fxaa_texel(const float4* __restrict__ img, int width, int height, int i, int j)
+{
+    i = i < 0 ? 0 : (i > width - 1 ? width - 1 : i);
+    j = j < 0 ? 0 : (j > height - 1 ? height - 1 : j);
+    const float4 p = img[(size_t)j * (size_t)width + (size_t)i];
+    return mk3(p.x, p.y, p.z);
+}
+__device__ __forceinline__ v3 fxaa_linear(const float4* __restrict__ img, int width, int height, float s, float t)
+{
+    const float u = s * (float)width - 0.5f, v = t * (float)height - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const int i0 = (int)fu, j0 = (int)fv;
+    const v3 t00 = fxaa_texel(img, width, height, i0, j0), t10 = fxaa_texel(img, width, height, i0 + 1, j0);
+    const v3 t01 = fxaa_texel(img, width, height, i0, j0 + 1), t11 = fxaa_texel(img, width, height, i0 + 1, j0 + 1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return add3(add3(add3(scale3(t00, w00), scale3(t10, w10)), scale3(t01, w01)), scale3(t11, w11));
+}
+__global__ __launch_bounds__(CRT_BLOCK) void crt_fxaa_kernel(CrtFrame F, const float4* __restrict__ src, float4* __restrict__ dst)
+{
+    int px, py;
+    if (!lane_pixel(F, px, py)) return;
+    const int W = F.width, H = F.height;
+    const float resx = (float)W, resy = (float)H;
+    const float uvx = (float)px / resx, uvy = (float)py / resy;
+    const v3 luma = mk3(0.299f, 0.587f, 0.114f);
+    const v3 rgb = fxaa_texel(src, W, H, px, py);
+    const float lumaNW = dot3(fxaa_texel(src, W, H, px - 1, py - 1), luma);
+    const float lumaNE = dot3(fxaa_texel(src, W, H, px + 1, py - 1), luma);
+    const float lumaSW = dot3(fxaa_texel(src, W, H, px - 1, py + 1), luma);
+    const float lumaSE = dot3(fxaa_texel(src, W, H, px + 1, py + 1), luma);
+    const float lumaM = dot3(rgb, luma);
+    float dirx = -((lumaNW + lumaNE) - (lumaSW + lumaSE));
+    float diry = ((lumaNW + lumaSW) - (lumaNE + lumaSE));
+    const float lumaSum = ((lumaNW + lumaNE) + lumaSW) + lumaSE;
+    const float dirReduce = fmaxf(lumaSum * (0.25f * (1.0f / 8.0f)), 1.0f / 128.0f);
+    const float rcpDirMin = 1.0f / (fminf(fabsf(dirx), fabsf(diry)) + dirReduce);
+    dirx = fminf(8.0f, fmaxf(-8.0f, dirx * rcpDirMin)) / resx;
+    diry = fminf(8.0f, fmaxf(-8.0f, diry * rcpDirMin)) / resy;
+    const v3 a0 = fxaa_linear(src, W, H, uvx + dirx * -0.166667f, uvy + diry * -0.166667f);
+    const v3 a1 = fxaa_linear(src, W, H, uvx + dirx * 0.166667f, uvy + diry * 0.166667f);
+    const v3 rgbA = scale3(add3(a0, a1), 0.5f);
+    const v3 b0 = fxaa_linear(src, W, H, uvx + dirx * -0.5f, uvy + diry * -0.5f);
+    const v3 b1 = fxaa_linear(src, W, H, uvx + dirx * 0.5f, uvy + diry * 0.5f);
+    const v3 rgbB = add3(scale3(rgbA, 0.5f), scale3(add3(b0, b1), 0.25f));
+    const float lumaB = dot3(rgbB, luma);
+    const float lumaMin = fminf(lumaM, fminf(fminf(lumaNW, lumaNE), fminf(lumaSW, lumaSE)));
+    const float lumaMax = fmaxf(lumaM, fmaxf(fmaxf(lumaNW, lumaNE), fmaxf(lumaSW, lumaSE)));
+    const v3 o = ((lumaB < lumaMin) || (lumaB > lumaMax)) ? rgbA : rgbB;
+    dst[(size_t)py * (size_t)W + (size_t)px] = make_float4(o.x, o.y, o.z, 1.0f);
+}
+
 // Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef):
 // convert_uchar_sat_rte(x * 255) / 255 per channel, in place (CRT_RENDER_UNORM8), and the packed bytes.
 __device__ __forceinline__ uint32_t unorm8(float x)

@@ -41,6 +41,7 @@ struct FrameSlot {
     EventSet es[2];                            // two sets, so the host may queue a slot's next frame before reading the last one's timing
     unsigned frames = 0;
     float4* out = nullptr;
+    float4* aux = nullptr; size_t auxPixels = 0;   // CRT_RENDER_FXAA: the unfiltered frame the filter reads (allocated on first use)
     CrtSuspended* susp = nullptr; uint32_t* suspCounters = nullptr; size_t suspCap = 0;   // straggler hand-off queue of this slot (count, head)
     uint32_t* ovf = nullptr; size_t ovfBlocks = 0;   // traversal-stack overflow area of this slot's launches (CrtStack), one block per workgroup
     uint32_t* order = nullptr; uint32_t* len = nullptr; uint32_t* cost = nullptr;   // feedback launch lists
@@ -220,7 +221,12 @@ int alloc_frame_buffers(int w, int h)
     if (g.rays) (void)hipFree(g.rays);
     if (g.bounceQueue) (void)hipFree(g.bounceQueue);
     g.rays = rays; g.bounceQueue = queue; g.bounceCap = pixels;
-    for (int i = 0; i < CRT_MAX_FRAMES_IN_FLIGHT; ++i) { if (g.slot[i].out) (void)hipFree(g.slot[i].out); g.slot[i].out = outs[i]; }
+    for (int i = 0; i < CRT_MAX_FRAMES_IN_FLIGHT; ++i) {
+        FrameSlot& fs = g.slot[i];
+        if (fs.out) (void)hipFree(fs.out);
+        fs.out = outs[i];
+        if (fs.aux) { (void)hipFree(fs.aux); fs.aux = nullptr; fs.auxPixels = 0; }
+    }
     g.width = w; g.height = h; g.readbackCount = 0;
     return CRT_OK;
 }
@@ -573,7 +579,7 @@ static void release_all()
                      g.texels, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount };
     for (FrameSlot& fs : g.slot) {
-        void* q[] = { fs.out, fs.ovf, fs.susp, fs.suspCounters, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
+        void* q[] = { fs.out, fs.aux, fs.ovf, fs.susp, fs.suspCounters, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
         for (void* p : q) if (p) (void)hipFree(p);
         if (fs.staging) (void)hipHostFree(fs.staging);
         if (fs.staged) (void)hipEventDestroy(fs.staged);
@@ -995,6 +1001,8 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
     const bool variant = g.wavefront != 0;
     if ((flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION)) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
+    const bool fxaa = (flags & CRT_RENDER_FXAA) != 0;
+    if (fxaa && g.groupSize <= 1 && g.nRanks > 1) return CRT_E_UNSUPPORTED;                  // the filter reads across band edges
     const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
                         && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
     int slot = 0;
@@ -1030,7 +1038,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0;
     }
     es.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
-    es.evPost = (flags & (CRT_RENDER_POSTPROCESS | CRT_RENDER_UNORM8)) != 0;
+    es.evPost = (flags & (CRT_RENDER_POSTPROCESS | CRT_RENDER_UNORM8 | CRT_RENDER_FXAA)) != 0;
     HIPCHK(hipEventRecord(es.ev[0], fs.stream));
     if (es.evRaygen) {
         crt_raygen_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, g.rays);
@@ -1052,11 +1060,38 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     if (es.evPost) {
         // upstream: Trace write_imagef's into an RGBA8 texture, PostProcess read_imagef's it back and write_imagef's again
         const bool unorm = (flags & CRT_RENDER_UNORM8) != 0, post = (flags & CRT_RENDER_POSTPROCESS) != 0;
-        if (unorm) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
-        if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
-        if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
-        HIPCHK(hipGetLastError());
-        if (isPrimary) RCCHK(wait_for_parts());
+        if (!fxaa) {
+            if (unorm) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+            if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+            if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+            HIPCHK(hipGetLastError());
+            if (isPrimary) RCCHK(wait_for_parts());
+        } else if (!isSecondary) {
+            // FXAA reads up to 5 pixels around its own in the Trace result, so it runs on the whole frame: a multi-device
+            // session gathers the raw bands first (the secondaries skip their per-pixel stages) and its first device filters
+            if (isPrimary) RCCHK(wait_for_parts());
+            CrtFrame FF = F;                                // every tile row, plain order
+            FF.order = nullptr; FF.cost = nullptr; FF.listLen = nullptr;
+            FF.rank = 0; FF.nRanks = 1;
+            FF.ownedTileRows = (g.height + CRT_TILE - 1) / CRT_TILE;
+            FF.gridBlocks = ((FF.ownedTileRows + 7) / 8) * 8 * FF.tilesX;
+            FF.slotsPerXcd = FF.gridBlocks / 8; FF.listCap = FF.slotsPerXcd;
+            const unsigned gridAll = (unsigned)FF.gridBlocks;
+            const size_t pixels = (size_t)g.width * (size_t)g.height;
+            if (fs.auxPixels < pixels) {
+                HIPCHK(hipStreamSynchronize(fs.stream));
+                if (fs.aux) (void)hipFree(fs.aux);
+                fs.aux = nullptr; fs.auxPixels = 0;
+                HIPCHK(hipMalloc(&fs.aux, pixels * sizeof(float4)));
+                fs.auxPixels = pixels;
+            }
+            if (unorm) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
+            HIPCHK(hipMemcpyAsync(fs.aux, fs.out, pixels * sizeof(float4), hipMemcpyDeviceToDevice, fs.stream));
+            crt_fxaa_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.aux, fs.out);
+            if (post) crt_postprocess_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
+            if (unorm) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipEventRecord(es.ev[3], fs.stream));
     }
     if (isSecondary) {

@@ -94,10 +94,11 @@ class Session:
             self.width, self.height = int(width), int(height)
 
     # ---- rendering through the mirrored Renderer ----
-    def render(self, sun_angle=None, postprocess=False, shadows=False, pipelined=False, refraction=False):
+    def render(self, sun_angle=None, postprocess=False, shadows=False, pipelined=False, refraction=False, fxaa=False):
         self.h.crth_set_postprocess(1 if postprocess else 0)
         self.h.crth_set_shadows(1 if shadows else 0)          # extension, off upstream
         self.h.crth_set_refraction(1 if refraction else 0)    # extension, off upstream
+        self.h.crth_set_fxaa(1 if fxaa else 0)                # extension: dead code upstream (kernel_main.cl:349)
         self.h.crth_set_pipelined(1 if pipelined else 0)      # frames in flight; output()/uploads wait
         frame = self.h.crth_render(float(self.scene.sun_angle if sun_angle is None else sun_angle))
         if frame == 0:

@@ -16,7 +16,7 @@ namespace {
     Camera camera;
     bool deviceReady = false;
     bool postProcess = true;   // upstream always runs PostProcess (Renderer.cpp:360-363)
-    bool shadows = false, pipelined = false, unorm8 = false, refraction = false;
+    bool shadows = false, pipelined = false, unorm8 = false, refraction = false, fxaa = false;
     std::vector<unsigned char> hostFrame8;
     float timeSeconds = 0.0f;
     unsigned frameIndex = 0;
@@ -50,6 +50,7 @@ Camera& Renderer::EditCamera() { return camera; }
 void Renderer::SetPostProcess(bool enabled) { postProcess = enabled; }
 void Renderer::SetShadows(bool enabled) { shadows = enabled; }
 void Renderer::SetRefraction(bool enabled) { refraction = enabled; }
+void Renderer::SetFXAA(bool enabled) { fxaa = enabled; }
 void Renderer::SetUnorm8(bool enabled) { unorm8 = enabled; }
 void Renderer::SetPipelined(bool enabled) { pipelined = enabled; }
 void Renderer::SetTime(float seconds) { timeSeconds = seconds; }
@@ -174,7 +175,7 @@ unsigned Renderer::Render(float sunAngle)
     CrtTraceArgs args;
     args.cameraPos[0] = camera.position.x; args.cameraPos[1] = camera.position.y; args.cameraPos[2] = camera.position.z;
     args.time = timeSeconds; args.numMeshes = g_NumMeshInstances; args.sunAngle = sunAngle;
-    const int flags = (postProcess ? CRT_RENDER_POSTPROCESS : 0) | (shadows ? CRT_RENDER_SHADOWS : 0) | (refraction ? CRT_RENDER_REFRACTION : 0) | (pipelined ? CRT_RENDER_ASYNC : 0) | (unorm8 ? CRT_RENDER_UNORM8 : 0);
+    const int flags = (postProcess ? CRT_RENDER_POSTPROCESS : 0) | (shadows ? CRT_RENDER_SHADOWS : 0) | (refraction ? CRT_RENDER_REFRACTION : 0) | (fxaa ? CRT_RENDER_FXAA : 0) | (pipelined ? CRT_RENDER_ASYNC : 0) | (unorm8 ? CRT_RENDER_UNORM8 : 0);
     if (!check(crt_render(&args, &camera.inverseView.m[0][0], &camera.inverseProjection.m[0][0], flags), "crt_render")) return 0;
     return ++frameIndex;
 }

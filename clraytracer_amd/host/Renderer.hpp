@@ -40,6 +40,7 @@ namespace Renderer
     void SetUnorm8(bool enabled);         // quantise like upstream's RGBA8 render target (hazard H8); MapOutputRGBA8() returns the bytes
     const unsigned char* MapOutputRGBA8();
     void SetShadows(bool enabled);        // extension: the shadow ray upstream leaves as a TODO (kernel_main.cl:256-258); off by default
+    void SetFXAA(bool enabled);           // extension: upstream's FXAA (kernel_main.cl:289-340) is dead code (call commented out, kernel_main.cl:349); runs it as the first PostProcess stage; off by default
     void SetRefraction(bool enabled);     // extension: upstream's README TODO "refraction / transculency": materials with MTL d < 1 transmit; off by default
     void SetPipelined(bool enabled);      // Render() returns without waiting (frames in flight); MapOutput()/uploads wait. Off by default (upstream clFinish()es)
     void SetTime(float seconds);          // TraceArgs.time (Window::GetTime upstream)

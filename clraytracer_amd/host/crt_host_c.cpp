@@ -93,6 +93,7 @@ void crth_resize(int width, int height)
 void crth_set_postprocess(int enabled) { Renderer::SetPostProcess(enabled != 0); }
 void crth_set_shadows(int enabled) { Renderer::SetShadows(enabled != 0); }
 void crth_set_refraction(int enabled) { Renderer::SetRefraction(enabled != 0); }
+void crth_set_fxaa(int enabled) { Renderer::SetFXAA(enabled != 0); }
 void crth_set_unorm8(int enabled) { Renderer::SetUnorm8(enabled != 0); }
 const unsigned char* crth_map_output_rgba8(void) { return hostOnly ? nullptr : Renderer::MapOutputRGBA8(); }
 void crth_set_pipelined(int enabled) { Renderer::SetPipelined(enabled != 0); }

@@ -54,6 +54,7 @@ void crth_get_camera(float invView[16], float invProj[16], float position[3]);
 void crth_resize(int width, int height);                     /* Renderer::OnWindowResize */
 void crth_set_postprocess(int enabled);
 void crth_set_shadows(int enabled);                          /* Renderer::SetShadows (extension) */
+void crth_set_fxaa(int enabled);                             /* Renderer::SetFXAA (extension) */
 void crth_set_refraction(int enabled);                       /* Renderer::SetRefraction (extension) */
 void crth_set_unorm8(int enabled);                           /* Renderer::SetUnorm8 (hazard H8) */
 const unsigned char* crth_map_output_rgba8(void);            /* Renderer::MapOutputRGBA8 */

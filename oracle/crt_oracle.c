@@ -625,6 +625,74 @@ void orc_postprocess(float* rgba, int width, int height, int row0, int row1)
 }
 
 /* ------------------------------------------------------------------------------------------
+ * kernel_main.cl:289-340  FXAA -- EXTENSION. Upstream lists FXAA in its README (README.md:9) but the function is dead:
+ * its only call is commented out (kernel_main.cl:349), it has no return statement, and it would read neighbours of an
+ * image PostProcess is rewriting in place. There is therefore no reference behaviour to match; what is restated here
+ * is the function's arithmetic as written, with the three gaps closed the obvious way: the result is the `rgb` it
+ * assigns last; neighbours are read from the UNMODIFIED frame (`src`) and written to `dst`; reads outside the image
+ * clamp to the edge (sampler-less read_imagef is undefined there). `uv` is PostProcess's p / resolution
+ * (kernel_main.cl:346) -- not the pixel centre, so the linear taps sit half a pixel up-left, as upstream's would.
+ * The sampler is CLK_NORMALIZED_COORDS_TRUE | CLK_FILTER_LINEAR | CLK_ADDRESS_CLAMP_TO_EDGE, evaluated as the OpenCL
+ * 1.2 specification defines it (8.2: i0 = floor(u - 0.5), a = frac(u - 0.5), weights (1-a)(1-b), a(1-b), (1-a)b, ab).
+ * Parity for this stage is UNPINNED (nothing of upstream's ever ran it); the HIP kernel must match this bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline f3 fxaa_texel(const float* img, int width, int height, int i, int j)
+{
+    const float* p = img + 4 * ((size_t)clampi(j, 0, height - 1) * (size_t)width + (size_t)clampi(i, 0, width - 1));
+    return f3_make(p[0], p[1], p[2]);
+}
+static inline f3 fxaa_linear(const float* img, int width, int height, float s, float t)
+{
+    const float u = s * (float)width - 0.5f, v = t * (float)height - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const int i0 = (int)fu, j0 = (int)fv;
+    const f3 t00 = fxaa_texel(img, width, height, i0, j0), t10 = fxaa_texel(img, width, height, i0 + 1, j0);
+    const f3 t01 = fxaa_texel(img, width, height, i0, j0 + 1), t11 = fxaa_texel(img, width, height, i0 + 1, j0 + 1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return f3_add(f3_add(f3_add(f3_scale(t00, w00), f3_scale(t10, w10)), f3_scale(t01, w01)), f3_scale(t11, w11));
+}
+void orc_fxaa(const float* src, float* dst, int width, int height, int row0, int row1)
+{
+    const float FXAA_SPAN_MAX = 8.0f, FXAA_REDUCE_MUL = 1.0f / 8.0f, FXAA_REDUCE_MIN = 1.0f / 128.0f;
+    const f3 luma = f3_make(0.299f, 0.587f, 0.114f);
+    const float resx = (float)width, resy = (float)height;
+    for (int j = row0; j < row1; ++j) {
+        for (int i = 0; i < width; ++i) {
+            const float uvx = (float)i / resx, uvy = (float)j / resy;
+            const f3 rgb = fxaa_texel(src, width, height, i, j);
+            /* 1st stage: find the edge */
+            const float lumaNW = f3_dot(fxaa_texel(src, width, height, i - 1, j - 1), luma);
+            const float lumaNE = f3_dot(fxaa_texel(src, width, height, i + 1, j - 1), luma);
+            const float lumaSW = f3_dot(fxaa_texel(src, width, height, i - 1, j + 1), luma);
+            const float lumaSE = f3_dot(fxaa_texel(src, width, height, i + 1, j + 1), luma);
+            const float lumaM = f3_dot(rgb, luma);
+            float dirx = -((lumaNW + lumaNE) - (lumaSW + lumaSE));
+            float diry = ((lumaNW + lumaSW) - (lumaNE + lumaSE));
+            const float lumaSum = ((lumaNW + lumaNE) + lumaSW) + lumaSE;
+            const float dirReduce = fmaxf(lumaSum * (0.25f * FXAA_REDUCE_MUL), FXAA_REDUCE_MIN);
+            const float rcpDirMin = 1.0f / (fminf(fabsf(dirx), fabsf(diry)) + dirReduce);
+            dirx = fminf(FXAA_SPAN_MAX, fmaxf(-FXAA_SPAN_MAX, dirx * rcpDirMin)) / resx;
+            diry = fminf(FXAA_SPAN_MAX, fmaxf(-FXAA_SPAN_MAX, diry * rcpDirMin)) / resy;
+            /* 2nd stage: blur along it */
+            const f3 a0 = fxaa_linear(src, width, height, uvx + dirx * -0.166667f, uvy + diry * -0.166667f);
+            const f3 a1 = fxaa_linear(src, width, height, uvx + dirx * 0.166667f, uvy + diry * 0.166667f);
+            const f3 rgbA = f3_scale(f3_add(a0, a1), 0.5f);
+            const f3 b0 = fxaa_linear(src, width, height, uvx + dirx * -0.5f, uvy + diry * -0.5f);
+            const f3 b1 = fxaa_linear(src, width, height, uvx + dirx * 0.5f, uvy + diry * 0.5f);
+            const f3 rgbB = f3_add(f3_scale(rgbA, 0.5f), f3_scale(f3_add(b0, b1), 0.25f));
+            const float lumaB = f3_dot(rgbB, luma);
+            const float lumaMin = fminf(lumaM, fminf(fminf(lumaNW, lumaNE), fminf(lumaSW, lumaSE)));
+            const float lumaMax = fmaxf(lumaM, fmaxf(fmaxf(lumaNW, lumaNE), fmaxf(lumaSW, lumaSE)));
+            const f3 out = ((lumaB < lumaMin) || (lumaB > lumaMax)) ? rgbA : rgbB;
+            float* q = dst + 4 * ((size_t)j * (size_t)width + (size_t)i);
+            q[0] = out.x; q[1] = out.y; q[2] = out.z; q[3] = 1.0f;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Hazard H8: upstream's render target is a GL_RGBA 8-bit UNORM texture (Renderer.cpp:63,192), so write_imagef
  * (kernel_main.cl:274,358) stores convert_uchar_sat_rte(x * 255) per channel and read_imagef (kernel_main.cl:347)
  * returns c / 255. orc_quantize_unorm8 applies that store+load to a float frame in place (OpenCL 1.2 spec 8.3.1.1:

@@ -120,6 +120,10 @@ void orc_trace(const OrcScene* s, const CrtTraceArgs* args, const float* rays, i
 void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                   int row0, int row1, float* out, OrcStats* stats, int nthreads, int extensions);
 void orc_postprocess(float* rgba, int width, int height, int row0, int row1);
+/* EXTENSION, parity unpinned: upstream's dead FXAA function (kernel_main.cl:289-340; call commented out at :349) made
+ * runnable -- result returned, neighbours read from the unmodified `src`, reads clamped to the edge. Runs BEFORE
+ * orc_postprocess in the chain upstream sketches (FXAA -> Saturation -> Reinhard -> Gamma -> Vignette). */
+void orc_fxaa(const float* src_rgba, float* dst_rgba, int width, int height, int row0, int row1);
 /* Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef), in place on a
  * float frame; and the bytes themselves. Upstream's displayed frame = pack(postprocess(quantize(trace))). */
 void orc_quantize_unorm8(float* rgba, int width, int height, int row0, int row1);

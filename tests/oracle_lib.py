@@ -60,6 +60,7 @@ def lib():
         L.orc_trace_ex.argtypes = [C.POINTER(OrcScene), C.POINTER(CrtTraceArgs), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.POINTER(OrcStats), C.c_int, C.c_int]
         L.orc_postprocess.restype = None; L.orc_postprocess.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_fxaa.restype = None; L.orc_fxaa.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_quantize_unorm8.restype = None; L.orc_quantize_unorm8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_pack_unorm8.restype = None; L.orc_pack_unorm8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_closest_hits.restype = None
@@ -73,6 +74,15 @@ def lib():
 def f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a.ctypes.data_as(C.POINTER(C.c_float)), a
+
+
+def fxaa(img, row0=0, row1=None):
+    """orc_fxaa on a float RGBA frame (extension; upstream's function is dead code, kernel_main.cl:289-340)."""
+    src = np.ascontiguousarray(img, np.float32)
+    h, w, _ = src.shape
+    dst = src.copy()
+    lib().orc_fxaa(src.ctypes.data, dst.ctypes.data, w, h, row0, h if row1 is None else row1)
+    return dst
 
 
 class Oracle:
@@ -113,6 +123,9 @@ class Oracle:
         h, w, _ = img.shape
         lib().orc_postprocess(img.ctypes.data, w, h, row0, h if row1 is None else row1)
         return img
+
+    def fxaa(self, img, row0=0, row1=None):
+        return fxaa(img, row0, row1)
 
     def quantize_unorm8(self, img):
         img = np.ascontiguousarray(img, np.float32).copy()
