@@ -18,7 +18,8 @@ Workload:
            round-robin to the ranks (replicated scene, no data-path collective); total work is fixed
            as N grows ("scaling": "strong"). torch.distributed (RCCL) is only used for the barrier
            and the MAX-over-ranks of the wall time.
-Rays = primary rays + secondary rays actually traced, counted on the device by an instrumented
+The N == 1 line also carries `config5_one_gpu`: the 3840x2160 frame on this one GPU (outside the timed region), the base
+of the N > 1 lines. Rays = primary rays + secondary rays actually traced, counted on the device by an instrumented
 launch outside the timed region (and checked against the oracle in tests/).
 
 The JSON line also carries
@@ -448,6 +449,28 @@ def main():
         if single is not None:
             out["single_gpu_same_workload"] = {"value": round(rays_per_frame / single / 1e6, 2), "unit": "Mrays/s",
                                                "ms_per_step": round(single * 1e3, 4), "note": "rank 0 alone rendering the whole frame, 10 frames, same mode"}
+        if n == 1 and not args.width and not args.height:
+            # the N = 1 point of BASELINE config 5 (the 3840x2160 frame the N > 1 lines tile over the ranks), so that a scaling
+            # curve has a base on the same workload; outside the contract's timed region
+            s.resize(3840, 2160)
+            a5, iv5, ip5 = s.trace_args()
+            q_args, q_iv, q_ip = C.byref(a5), iv5.ctypes.data_as(fp), ip5.ctypes.data_as(fp)
+            s.render_raw(8 | (32 if args.shadows else 0))
+            rays5 = s.counters()["rays"]
+            for _ in range(5):
+                _lib.check(crt_render(q_args, q_iv, q_ip, flags), "crt_render")
+            _lib.check(hip.crt_sync(), "crt_sync")
+            k5 = max(10, min(50, args.steps))
+            t0 = time.perf_counter()
+            for _ in range(k5):
+                rc = crt_render(q_args, q_iv, q_ip, flags)
+            _lib.check(hip.crt_sync(), "crt_sync")
+            dt5 = (time.perf_counter() - t0) / k5
+            _lib.check(rc, "crt_render")
+            out["config5_one_gpu"] = {"value": round(rays5 / dt5 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt5 * 1e3, 4),
+                                      "rays_per_frame": rays5, "frames": k5,
+                                      "note": "the same scene at 3840x2160 on this one GPU (BASELINE config 5 at N = 1): the base of the N > 1 lines"}
+            s.resize(width, height)
         if n == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
