@@ -69,14 +69,18 @@ CASES = [  # seed, triangles per mesh, grid, instance kinds
 ]
 
 
-@pytest.mark.parametrize("seed,sizes,grid,kinds", CASES, ids=[f"seed{c[0]}" for c in CASES])
-def test_pathological_scenes_bit_exact(tmp_path, nthreads, seed, sizes, grid, kinds):
-    rng = np.random.default_rng(seed)
+def build_scene(tmp_path, rng, seed, sizes, grid, kinds):
     paths = [scenes._write_mesh(str(tmp_path), f"soup{i}", soup(rng, n, grid, degenerate=True), [((0.7, 0.5, 0.9), None)]) for i, n in enumerate(sizes)]
     sky = str(tmp_path / "sky.ppm")
     scenes.write_ppm(sky, scenes._skybox(64, 32))
     insts = [scenes.Instance(i % len(sizes), 0xFFFF, matrices(rng, kind)) for i, kind in enumerate(kinds)]
-    sc = scenes.Scene(f"fuzz{seed}", str(tmp_path), sky, paths, insts, (0.5, 1.0, 9.0), scenes._normalize((-0.05, -0.1, -1.0)))
+    return scenes.Scene(f"fuzz{seed}", str(tmp_path), sky, paths, insts, (0.5, 1.0, 9.0), scenes._normalize((-0.05, -0.1, -1.0)))
+
+
+@pytest.mark.parametrize("seed,sizes,grid,kinds", CASES, ids=[f"seed{c[0]}" for c in CASES])
+def test_pathological_scenes_bit_exact(tmp_path, nthreads, seed, sizes, grid, kinds):
+    rng = np.random.default_rng(seed)
+    sc = build_scene(tmp_path, rng, seed, sizes, grid, kinds)
     with np.errstate(all="ignore"), driver.Session(208, 120, device=0) as s:
         s.load_scene(sc)
         a = s.arenas()
@@ -98,3 +102,33 @@ def test_pathological_scenes_bit_exact(tmp_path, nthreads, seed, sizes, grid, ki
             diff = np.nonzero((bits(frame) != bits(want)).any(axis=2))
             # skybox texel flips from the double atan2/acos (glibc vs OCML) are the one tolerated difference
             assert len(diff[0]) <= 2, f"camera {cam}: {len(diff[0])} pixels differ, first {diff[0][:4]},{diff[1][:4]}"
+
+
+@pytest.mark.parametrize("seed,sizes,grid,kinds", CASES[1:], ids=[f"seed{c[0]}" for c in CASES[1:]])
+def test_pathological_scenes_extensions_and_device_build(tmp_path, nthreads, seed, sizes, grid, kinds):
+    """The same scenes through the opt-in paths: shadow rays (any-hit traversal), the device BVH builder (must reproduce the
+    host builder's bytes on ties and unsplittable leaves), frames in flight."""
+    rng = np.random.default_rng(seed)
+    sc = build_scene(tmp_path, rng, seed, sizes, grid, kinds)
+    with np.errstate(all="ignore"), driver.Session(208, 120, device=0) as s:
+        s.load_scene(sc)
+        a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in s.arenas().items()}
+        orc = oracle_lib.Oracle(a, nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        rays = orc.raygen(s.width, s.height, iv, ip)
+        s.render_raw(8 | 32)
+        want, st = orc.trace(rays, pos, sc.sun_angle, shadows=True)
+        assert s.counters() == st and (st["shadowRays"] > 0 or seed == 6)       # seed 6: every hit has a NaN t, nothing is lit
+        assert ((bits(s.read_output()) != bits(want)).any(axis=2)).sum() <= 2
+        s.render_raw(0)
+        plain = s.read_output().copy()
+        for _ in range(4):
+            s.render_raw(4)
+        assert np.array_equal(bits(s.read_output()), bits(plain))
+    with np.errstate(all="ignore"), driver.Session(208, 120, device=0) as s:
+        s.load_scene(sc, device_bvh_build=True)
+        b = s.arenas()
+        for k in ("tris", "nodes", "roots", "instances"):
+            assert a[k].tobytes() == b[k].tobytes(), k
+        s.render_raw(0)
+        assert np.array_equal(bits(s.read_output()), bits(plain))
