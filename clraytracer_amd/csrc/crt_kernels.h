@@ -160,6 +160,44 @@ __global__ void crt_identity_order_kernel(uint32_t* __restrict__ order, uint32_t
     if (i < 8 * slotsPerXcd) order[(i / slotsPerXcd) * listCap + (i % slotsPerXcd)] = (uint32_t)(i % slotsPerXcd);
 }
 
+// ---- per-pixel stages behind Trace, shared by their own launches and by the Trace kernel's epilogue ---------------------------
+// PostProcess (kernel_main.cl:342-359, MathAndSTL.cl:132-169): Saturation 1.2 -> Reinhard (white 0.8) + gamma 1.55 -> gamma 1.2
+// -> Vignette; uv = p / resolution.
+__device__ __forceinline__ v3 post_pixel(v3 rgb, int px, int py, int width, int height)
+{
+    const float uvx = (float)px / (float)width, uvy = (float)py / (float)height;
+    const float P = sqrtf((rgb.x * rgb.x) * 0.299f + ((rgb.y * rgb.y) * 0.587f) + ((rgb.z * rgb.z) * 0.114f));
+    const v3 Pv = mk3(P, P, P);
+    rgb = add3(Pv, scale3(sub3(rgb, Pv), 1.2f));
+    const v3 lw = mk3(0.2126f, 0.7152f, 0.0722f);
+    const float max_white_l = 0.8f;
+    const float l_old = dot3(rgb, lw);
+    const float numerator = l_old * (1.0f + (l_old / (max_white_l * max_white_l)));
+    const float l_new = numerator / (1.0f + l_old);
+    const float l_in = dot3(rgb, lw);
+    rgb = scale3(rgb, l_new / l_in);
+    const float ig = 1.0f / 1.55f;
+    rgb = mk3(powf(rgb.x, ig), powf(rgb.y, ig), powf(rgb.z, ig));
+    const float oneDivGamma = 1.0f / 1.2f;
+    rgb = mk3(powf(rgb.x, oneDivGamma), powf(rgb.y, oneDivGamma), powf(rgb.z, oneDivGamma));
+    const float vx = uvx * (1.0f - uvy), vy = uvy * (1.0f - uvx);
+    float vig = (vx * vy) * 15.0f;
+    vig = powf(vig, 0.15f);
+    return scale3(rgb, vig);
+}
+// Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef):
+// convert_uchar_sat_rte(x * 255) / 255 per channel (CRT_RENDER_UNORM8), and the byte itself.
+__device__ __forceinline__ uint32_t unorm8(float x)
+{
+    const float v = x * 255.0f;
+    if (!(v == v) || v <= 0.0f) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (uint32_t)rintf(v);
+}
+__device__ __forceinline__ float quantize1(float x) { return (float)unorm8(x) / 255.0f; }
+#define CRT_EPILOGUE_QUANTIZE 1   // CrtFrame::epilogue bits
+#define CRT_EPILOGUE_POST 2
+
 // kernel Trace (kernel_main.cl:164-275) with RayGen (kernel_main.cl:277-287) fused: the ray
 // direction is computed with the same arithmetic RayGen stores, so the 24.9 MB ray buffer
 // round-trip disappears. One thread per pixel, both bounces.
@@ -216,7 +254,18 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
         asm volatile("" : "+s"(b2), "+v"(lane2));
         int qx, qy;
         (void)lane_pixel(F, qx, qy, nullptr, nullptr, b2, lane2);
-        out[(size_t)qy * (size_t)F.width + (size_t)qx] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
+        // the per-pixel stages that follow Trace upstream (its RGBA8 render target, PostProcess) applied to the value in
+        // registers: no second and third pass over the frame (wave-uniform branches)
+        v3 rgb = ps.result;
+        if (F.epilogue & CRT_EPILOGUE_QUANTIZE) rgb = mk3(quantize1(rgb.x), quantize1(rgb.y), quantize1(rgb.z));
+        if (F.epilogue & CRT_EPILOGUE_POST) {
+            // opaque copies: otherwise (float)width / (float)height of RayGen are kept alive (spilled) through both traversals
+            int w2 = F.width, h2 = F.height;
+            asm volatile("" : "+s"(w2), "+s"(h2));
+            rgb = post_pixel(rgb, qx, qy, w2, h2);
+            if (F.epilogue & CRT_EPILOGUE_QUANTIZE) rgb = mk3(quantize1(rgb.x), quantize1(rgb.y), quantize1(rgb.z));
+        }
+        out[(size_t)qy * (size_t)F.width + (size_t)qx] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
     }
     if (F.cost && costSlot >= 0) {      // per-tile cost of this frame (wave-uniform value, one store)
         // the four quadrant waves of a split tile each add half their cycles: about what the tile would take as one wave
@@ -423,33 +472,15 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_raygen_kernel(CrtFrame F, float
     o[0] = d.x; o[1] = d.y; o[2] = d.z;
 }
 
-// kernel PostProcess (kernel_main.cl:342-359, MathAndSTL.cl:132-169) on the float frame
+// kernel PostProcess (kernel_main.cl:342-359, MathAndSTL.cl:132-169) on the float frame, as its own launch (the default Trace
+// kernel applies post_pixel in its epilogue instead; this launch serves FXAA frames and the kernel variants)
 __global__ __launch_bounds__(CRT_BLOCK) void crt_postprocess_kernel(CrtFrame F, float4* __restrict__ img)
 {
     int px, py;
     if (!lane_pixel(F, px, py)) return;
     const size_t idx = (size_t)py * (size_t)F.width + (size_t)px;
-    const float uvx = (float)px / (float)F.width, uvy = (float)py / (float)F.height;
-    float4 p = img[idx];
-    v3 rgb = mk3(p.x, p.y, p.z);
-    const float P = sqrtf((rgb.x * rgb.x) * 0.299f + ((rgb.y * rgb.y) * 0.587f) + ((rgb.z * rgb.z) * 0.114f));
-    const v3 Pv = mk3(P, P, P);
-    rgb = add3(Pv, scale3(sub3(rgb, Pv), 1.2f));
-    const v3 lw = mk3(0.2126f, 0.7152f, 0.0722f);
-    const float max_white_l = 0.8f;
-    const float l_old = dot3(rgb, lw);
-    const float numerator = l_old * (1.0f + (l_old / (max_white_l * max_white_l)));
-    const float l_new = numerator / (1.0f + l_old);
-    const float l_in = dot3(rgb, lw);
-    rgb = scale3(rgb, l_new / l_in);
-    const float ig = 1.0f / 1.55f;
-    rgb = mk3(powf(rgb.x, ig), powf(rgb.y, ig), powf(rgb.z, ig));
-    const float oneDivGamma = 1.0f / 1.2f;
-    rgb = mk3(powf(rgb.x, oneDivGamma), powf(rgb.y, oneDivGamma), powf(rgb.z, oneDivGamma));
-    const float vx = uvx * (1.0f - uvy), vy = uvy * (1.0f - uvx);
-    float vig = (vx * vy) * 15.0f;
-    vig = powf(vig, 0.15f);
-    rgb = scale3(rgb, vig);
+    const float4 p = img[idx];
+    const v3 rgb = post_pixel(mk3(p.x, p.y, p.z), px, py, F.width, F.height);
     img[idx] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
 }
 
@@ -511,20 +542,13 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_fxaa_kernel(CrtFrame F, const f
 
 // Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef):
 // convert_uchar_sat_rte(x * 255) / 255 per channel, in place (CRT_RENDER_UNORM8), and the packed bytes.
-__device__ __forceinline__ uint32_t unorm8(float x)
-{
-    const float v = x * 255.0f;
-    if (!(v == v) || v <= 0.0f) return 0u;
-    if (v >= 255.0f) return 255u;
-    return (uint32_t)rintf(v);
-}
 __global__ __launch_bounds__(CRT_BLOCK) void crt_quantize_kernel(CrtFrame F, float4* __restrict__ img)
 {
     int px, py;
     if (!lane_pixel(F, px, py)) return;
     const size_t idx = (size_t)py * (size_t)F.width + (size_t)px;
     const float4 p = img[idx];
-    img[idx] = make_float4((float)unorm8(p.x) / 255.0f, (float)unorm8(p.y) / 255.0f, (float)unorm8(p.z) / 255.0f, (float)unorm8(p.w) / 255.0f);
+    img[idx] = make_float4(quantize1(p.x), quantize1(p.y), quantize1(p.z), quantize1(p.w));
 }
 __global__ void crt_pack_unorm8_kernel(const float4* __restrict__ img, uint32_t* __restrict__ out, size_t pixels)
 {

@@ -926,8 +926,10 @@ static int sort_for_next_frame(const CrtFrame& F, FrameSlot& fs, bool pipelined)
 }
 
 // The Trace launch(es) of one frame, by kernel structure (default: megakernel with feedback launch lists).
-static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid, FrameSlot& fs)
+// *epilogueApplied: the launch was the default megakernel, which applies F.epilogue (RGBA8 target / PostProcess) itself
+static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid, FrameSlot& fs, bool* epilogueApplied)
 {
+    *epilogueApplied = false;
     const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
     if (count) HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), fs.stream));
     if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
@@ -967,6 +969,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         else { crt_trace_fast_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, Q); crt_straggler_kernel<false><<<sgrid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, Q); }
     } else {
         // default megakernel: <COUNT, STAMP, SHADOW, TLAS, REFRACT>
+        *epilogueApplied = true;
         const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, refract = (flags & CRT_RENDER_REFRACTION) != 0;
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
         const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
@@ -1045,7 +1048,12 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(es.ev[1], fs.stream));
     }
-    rc = launch_trace(S, F, flags, grid, fs);
+    // upstream's per-pixel stages behind Trace (its RGBA8 render target, PostProcess) ride in the Trace kernel's epilogue
+    // unless FXAA sits between them (it reads neighbours) or a kernel variant without the epilogue is selected
+    const bool unorm = (flags & CRT_RENDER_UNORM8) != 0, post = (flags & CRT_RENDER_POSTPROCESS) != 0;
+    if (!fxaa) F.epilogue = (unorm ? CRT_EPILOGUE_QUANTIZE : 0u) | (post ? CRT_EPILOGUE_POST : 0u);
+    bool fused = false;
+    rc = launch_trace(S, F, flags, grid, fs, &fused);
     if (rc) return rc;
     // in-process multi-GPU, primary device: the frame is complete when every secondary's bands have arrived -- its last
     // event is recorded behind waits for their partDone events (recorded before this call: the dispatcher submits the
@@ -1059,12 +1067,13 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     HIPCHK(hipEventRecord(es.ev[2], fs.stream));
     if (es.evPost) {
         // upstream: Trace write_imagef's into an RGBA8 texture, PostProcess read_imagef's it back and write_imagef's again
-        const bool unorm = (flags & CRT_RENDER_UNORM8) != 0, post = (flags & CRT_RENDER_POSTPROCESS) != 0;
         if (!fxaa) {
-            if (unorm) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
-            if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
-            if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
-            HIPCHK(hipGetLastError());
+            if (!fused) {
+                if (unorm) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+                if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+                if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+                HIPCHK(hipGetLastError());
+            }
             if (isPrimary) RCCHK(wait_for_parts());
         } else if (!isSecondary) {
             // FXAA reads up to 5 pixels around its own in the Trace result, so it runs on the whole frame: a multi-device

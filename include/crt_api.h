@@ -158,7 +158,9 @@ void* crt_output_device_ptr(void);
 int crt_owned_rows(void);                                     /* rows this rank renders per frame */
 
 /* Timing of the last crt_render measured with HIP events on the launch stream.
- * which: 0 = whole frame, 1 = RayGen (only with WRITE_RAYS), 2 = Trace, 3 = PostProcess. */
+ * which: 0 = whole frame, 1 = RayGen (only with WRITE_RAYS), 2 = Trace, 3 = PostProcess (and the RGBA8 stores, FXAA) --
+ * close to zero for the default kernel, which applies PostProcess and the RGBA8 target to the pixel in its registers
+ * before storing it; the stages run as launches of their own behind FXAA and the opt-in kernel variants. */
 float crt_last_kernel_ms(int which);
 /* Event timing accumulated over every frame since the last reset. Read back lazily per frame slot, so this does
  * not serialise ASYNC frames the way asking crt_last_kernel_ms after each frame would. With frames in flight the

@@ -15,11 +15,17 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     the same bits and counts the same work as the default megakernel. (Round 1's `persistent` and `lds` structures were
     retired in round 2; DESIGN.md keeps their measurements.)"""
     sc = scenes.get("tiny")
+    POST, ASYNC, UNORM8 = 1, 4, 64
+    stages = (POST, UNORM8, POST | UNORM8, POST | UNORM8 | ASYNC)
     monkeypatch.delenv("CRT_KERNEL", raising=False)
     with driver.Session(256, 144, device=0) as s:
         s.load_scene(sc)
         s.render_raw(FLAG_COUNT)
         ref = s.read_output(); ref_cnt = s.counters()
+        # the default kernel applies the RGBA8 target / PostProcess in its epilogue ...
+        fused = []
+        for f in stages:
+            s.render_raw(f); fused.append(s.read_output().copy())
     monkeypatch.setenv("CRT_KERNEL", variant)
     with driver.Session(256, 144, device=0) as s:
         s.load_scene(sc)
@@ -27,8 +33,13 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
         got = s.read_output(); cnt = s.counters()
         s.render_raw(0)
         got2 = s.read_output()
+        # ... the variant runs them as launches of their own (crt_quantize_kernel, crt_postprocess_kernel): same bits
+        for f, want in zip(stages, fused):
+            s.render_raw(f)
+            assert np.array_equal(bits(s.read_output()), bits(want)), f
     assert np.array_equal(bits(got), bits(ref)) and np.array_equal(bits(got2), bits(ref))
     assert cnt == ref_cnt
+    assert not np.array_equal(bits(fused[0]), bits(ref)) and not np.array_equal(bits(fused[2]), bits(fused[0]))
 
 
 @pytest.mark.parametrize("name", ["tiny", "multi-1M", "sponza-sibenik"])
