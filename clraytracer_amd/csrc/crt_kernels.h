@@ -536,7 +536,10 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_fxaa_kernel(CrtFrame F, const f
     const float lumaB = dot3(rgbB, luma);
     const float lumaMin = fminf(lumaM, fminf(fminf(lumaNW, lumaNE), fminf(lumaSW, lumaSE)));
     const float lumaMax = fmaxf(lumaM, fmaxf(fmaxf(lumaNW, lumaNE), fmaxf(lumaSW, lumaSE)));
-    const v3 o = ((lumaB < lumaMin) || (lumaB > lumaMax)) ? rgbA : rgbB;
+    v3 o = ((lumaB < lumaMin) || (lumaB > lumaMax)) ? rgbA : rgbB;
+    // the stages behind the filter, on the value in registers: PostProcess, then the store into upstream's RGBA8 target
+    if (F.epilogue & CRT_EPILOGUE_POST) o = post_pixel(o, px, py, W, H);
+    if (F.epilogue & CRT_EPILOGUE_QUANTIZE) o = mk3(quantize1(o.x), quantize1(o.y), quantize1(o.z));
     dst[(size_t)py * (size_t)W + (size_t)px] = make_float4(o.x, o.y, o.z, 1.0f);
 }
 

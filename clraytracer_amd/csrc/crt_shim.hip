@@ -926,8 +926,9 @@ static int sort_for_next_frame(const CrtFrame& F, FrameSlot& fs, bool pipelined)
 }
 
 // The Trace launch(es) of one frame, by kernel structure (default: megakernel with feedback launch lists).
+// `out`: the frame the launch writes (the slot's frame, or its unfiltered copy when FXAA follows).
 // *epilogueApplied: the launch was the default megakernel, which applies F.epilogue (RGBA8 target / PostProcess) itself
-static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid, FrameSlot& fs, bool* epilogueApplied)
+static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid, FrameSlot& fs, float4* out, bool* epilogueApplied)
 {
     *epilogueApplied = false;
     const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
@@ -942,17 +943,17 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         }
         g.stampWaves = grid;
         HIPCHK(hipMemsetAsync(g.stamps, 0, need, fs.stream));
-        crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.stamps);
+        crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps);
     } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
         const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
         const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
         HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), fs.stream));
         if (count) {
-            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
         } else {
-            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
         }
     } else if (!count && !(flags & CRT_RENDER_SHADOWS) && F.suspendAt > 0 && S.numInstances <= 64 && g.forceTlas != 1) {
         // plain launch with straggler hand-off: the trace kernel, then the kernel that finishes the suspended rays
@@ -965,8 +966,8 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         const unsigned resident = (unsigned)g.numCUs * 4u * CRT_WAVES_PER_SIMD / 2u;      // half the machine's wave slots: each wave loops over packets
         if (sgrid > resident) sgrid = resident;
         if (sgrid < 1) sgrid = 1;
-        if (refract) { crt_trace_fast_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, Q); crt_straggler_kernel<true><<<sgrid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, Q); }
-        else { crt_trace_fast_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, Q); crt_straggler_kernel<false><<<sgrid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, Q); }
+        if (refract) { crt_trace_fast_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); crt_straggler_kernel<true><<<sgrid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); }
+        else { crt_trace_fast_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); crt_straggler_kernel<false><<<sgrid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); }
     } else {
         // default megakernel: <COUNT, STAMP, SHADOW, TLAS, REFRACT>
         *epilogueApplied = true;
@@ -974,8 +975,8 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
         const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
         const bool allSteps = !count && F.smallPacket >= (uint32_t)CRT_BLOCK;      // frames in flight: the instantiation without the vote
-#define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) do { if (allSteps) crt_trace_kernel<C_, false, S_, T_, R_, !C_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); \
-                                               else crt_trace_kernel<C_, false, S_, T_, R_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, fs.out, g.counters); } while (0)
+#define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) do { if (allSteps) crt_trace_kernel<C_, false, S_, T_, R_, !C_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters); \
+                                               else crt_trace_kernel<C_, false, S_, T_, R_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters); } while (0)
 #define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) CRT_LAUNCH_TRACE3(C_, S_, T_, true); else CRT_LAUNCH_TRACE3(C_, S_, T_, false); } while (0)
 #define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) CRT_LAUNCH_TRACE2(C_, S_, true); else CRT_LAUNCH_TRACE2(C_, S_, false); } while (0)
         if (count) { if (shadow) CRT_LAUNCH_TRACE(true, true); else CRT_LAUNCH_TRACE(true, false); }
@@ -1049,11 +1050,23 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         HIPCHK(hipEventRecord(es.ev[1], fs.stream));
     }
     // upstream's per-pixel stages behind Trace (its RGBA8 render target, PostProcess) ride in the Trace kernel's epilogue
-    // unless FXAA sits between them (it reads neighbours) or a kernel variant without the epilogue is selected
+    // unless a kernel variant without the epilogue is selected. FXAA sits between them and reads neighbours: on one device
+    // Trace then writes the slot's second buffer (its pixels already through the RGBA8 target) and the filter writes the
+    // frame, applying PostProcess and the final RGBA8 store in ITS epilogue -- two launches, no copy.
     const bool unorm = (flags & CRT_RENDER_UNORM8) != 0, post = (flags & CRT_RENDER_POSTPROCESS) != 0;
+    const bool fxaaLocal = fxaa && g.groupSize <= 1;
+    const size_t framePixels = (size_t)g.width * (size_t)g.height;
+    if (fxaa && !(g.groupSize > 1 && g.primary != G) && fs.auxPixels < framePixels) {
+        HIPCHK(hipStreamSynchronize(fs.stream));
+        if (fs.aux) (void)hipFree(fs.aux);
+        fs.aux = nullptr; fs.auxPixels = 0;
+        HIPCHK(hipMalloc(&fs.aux, framePixels * sizeof(float4)));
+        fs.auxPixels = framePixels;
+    }
     if (!fxaa) F.epilogue = (unorm ? CRT_EPILOGUE_QUANTIZE : 0u) | (post ? CRT_EPILOGUE_POST : 0u);
+    else if (fxaaLocal) F.epilogue = unorm ? CRT_EPILOGUE_QUANTIZE : 0u;
     bool fused = false;
-    rc = launch_trace(S, F, flags, grid, fs, &fused);
+    rc = launch_trace(S, F, flags, grid, fs, fxaaLocal ? fs.aux : fs.out, &fused);
     if (rc) return rc;
     // in-process multi-GPU, primary device: the frame is complete when every secondary's bands have arrived -- its last
     // event is recorded behind waits for their partDone events (recorded before this call: the dispatcher submits the
@@ -1086,19 +1099,14 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
             FF.gridBlocks = ((FF.ownedTileRows + 7) / 8) * 8 * FF.tilesX;
             FF.slotsPerXcd = FF.gridBlocks / 8; FF.listCap = FF.slotsPerXcd;
             const unsigned gridAll = (unsigned)FF.gridBlocks;
-            const size_t pixels = (size_t)g.width * (size_t)g.height;
-            if (fs.auxPixels < pixels) {
-                HIPCHK(hipStreamSynchronize(fs.stream));
-                if (fs.aux) (void)hipFree(fs.aux);
-                fs.aux = nullptr; fs.auxPixels = 0;
-                HIPCHK(hipMalloc(&fs.aux, pixels * sizeof(float4)));
-                fs.auxPixels = pixels;
+            if (fxaaLocal) {
+                if (unorm && !fused) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.aux);
+            } else {
+                if (unorm) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
+                HIPCHK(hipMemcpyAsync(fs.aux, fs.out, framePixels * sizeof(float4), hipMemcpyDeviceToDevice, fs.stream));
             }
-            if (unorm) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
-            HIPCHK(hipMemcpyAsync(fs.aux, fs.out, pixels * sizeof(float4), hipMemcpyDeviceToDevice, fs.stream));
+            FF.epilogue = (unorm ? CRT_EPILOGUE_QUANTIZE : 0u) | (post ? CRT_EPILOGUE_POST : 0u);
             crt_fxaa_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.aux, fs.out);
-            if (post) crt_postprocess_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
-            if (unorm) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(es.ev[3], fs.stream));

@@ -15,8 +15,8 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     the same bits and counts the same work as the default megakernel. (Round 1's `persistent` and `lds` structures were
     retired in round 2; DESIGN.md keeps their measurements.)"""
     sc = scenes.get("tiny")
-    POST, ASYNC, UNORM8 = 1, 4, 64
-    stages = (POST, UNORM8, POST | UNORM8, POST | UNORM8 | ASYNC)
+    POST, ASYNC, UNORM8, FXAA = 1, 4, 64, 512
+    stages = (POST, UNORM8, POST | UNORM8, POST | UNORM8 | ASYNC, FXAA | UNORM8, FXAA | POST | UNORM8)
     monkeypatch.delenv("CRT_KERNEL", raising=False)
     with driver.Session(256, 144, device=0) as s:
         s.load_scene(sc)
