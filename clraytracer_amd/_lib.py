@@ -112,6 +112,7 @@ HOST_API = {
     "crth_set_mesh_cache": (None, [C.c_int]),
     "crth_qlz_decompress": (C.c_size_t, [_vp, _sz, _vp, _sz]),
     "crth_qlz_store": (C.c_size_t, [_vp, _sz, _vp]),
+    "crth_qlz_compress": (C.c_size_t, [_vp, _sz, _vp]),
     "crth_jpeg_decode": (C.c_size_t, [_vp, _sz, _vp, _sz, C.POINTER(C.c_int), C.POINTER(C.c_char_p)]),
     "crth_set_asset_root": (None, [C.c_char_p]),
     "crth_push_textures": (None, []),

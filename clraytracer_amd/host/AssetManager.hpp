@@ -32,6 +32,7 @@ ObjMesh* AssetManager_LoadMeshFromDisk(const char* path, Tri* triArena, size_t m
 bool MeshCache_IsFresh(const char* cache, const char* source);
 size_t MeshCache_QlzDecompress(const unsigned char* src, size_t srcLen, unsigned char* dst, size_t dstCap);
 size_t MeshCache_QlzStore(const unsigned char* src, size_t size, unsigned char* dst);
+size_t MeshCache_QlzCompress(const unsigned char* src, size_t size, unsigned char* dst);   // dst: size + 400 bytes
 void AssetManager_Initialize();
 void AssetManager_Destroy();
 

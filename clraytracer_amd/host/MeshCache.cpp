@@ -14,8 +14,16 @@
 //           write cursor is hashed, after a match every position up to the match start (the inside of a match is
 //           never hashed). Flag 0 = literals: 1..4 at a time (as many as there are consecutive 0 flags in the low
 //           nibble) while more than 10 bytes remain, then byte by byte to the end.
-// Writing uses the format's own escape for incompressible data -- a header with C = 0 followed by the bytes -- which
-// every QuickLZ decoder (upstream's included) accepts; the cache is bigger than upstream's but interchangeable.
+// Writing: MeshCache_QlzCompress produces the bytes upstream's qlz_compress produces (level 1, 64-bit x86 build:
+// 4-byte fetches), so a cache written here is the file upstream would have written for the same triangles:
+//   the compressor walks the input keeping, per 12-bit hash, the last position it stood on and the 4 bytes it saw there.
+//   At each step: the slot's 3 bytes equal the current ones and the slot is set (position 0 counts as unset) and the
+//   candidate is more than 2 bytes back -- or exactly 1 back inside a run of 7 equal bytes after >= 3 literals -- ->
+//   a match (3 bytes if the 4th byte differs; else 4, 5, or as many as agree up to 255 and never into the last 4
+//   bytes); otherwise a literal. The slot is overwritten either way; positions inside a match are not visited.
+//   The last 10 bytes are literals (their first 7 still refresh the table). A control word is flushed after 31
+//   tokens; at a flush past half of the input with less than 1/32 saved, the stream is abandoned and the data is
+//   stored with C = 0 (MeshCache_QlzStore). Inputs under 216 bytes get the short header.
 #include "AssetManager.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -107,6 +115,95 @@ size_t MeshCache_QlzStore(const unsigned char* src, size_t size, unsigned char* 
     return size + 9;
 }
 
+// QuickLZ 1.5.0 level-1 compressor (format and policy in the header comment). dst needs size + 400 bytes.
+// Returns the stream length including its header; 0 for size 0.
+size_t MeshCache_QlzCompress(const unsigned char* src, size_t size, unsigned char* dst)
+{
+    if (size == 0 || size > 0xffffffffull - 400) return 0;
+    const size_t head = size < 216 ? 3 : 9;
+    struct Slot { uint32_t pos, seen; };                         // last position with this hash (0 = none) and the 4 bytes there
+    std::vector<Slot> table(4096, Slot{ 0u, 0u });
+    auto hashOf = [](uint32_t v) { return ((v >> 12) ^ v) & 4095u; };
+    auto rd4 = [&](size_t at) { return (uint32_t)src[at] | (uint32_t)src[at + 1] << 8 | (uint32_t)src[at + 2] << 16 | (uint32_t)src[at + 3] << 24; };
+
+    unsigned char* const body = dst + head;
+    const size_t last = size - 1;
+    size_t in = 0, out = 4, ctlAt = 0;                           // `out`/`ctlAt` index body[]; the first control word sits at 0
+    uint32_t ctl = 1u << 31;                                     // flags enter at bit 31; the sentinel reaching bit 0 = 31 tokens
+    unsigned literalsInARow = 0;
+    bool stored = false;
+    auto putCtl = [&](uint32_t v) { for (int i = 0; i < 4; ++i) body[ctlAt + i] = (unsigned char)(v >> (8 * i)); };
+    auto flushIfFull = [&]() {
+        if ((ctl & 1u) == 0) return;
+        putCtl((ctl >> 1) | (1u << 31));
+        ctlAt = out; out += 4; ctl = 1u << 31;
+    };
+
+    // positions at which a match may still start: it must end before the last 4 bytes and a 6-byte look-ahead stays inside
+    const bool hasMatchZone = size >= 11;
+    const size_t lastMatchStart = hasMatchZone ? last - 10 : 0;
+    while (hasMatchZone && in <= lastMatchStart) {
+        if (ctl & 1u) {
+            if (in > (size >> 1) && out > in - (in >> 5)) { stored = true; break; }   // less than 1/32 saved past the middle: give up
+            flushIfFull();
+        }
+        const uint32_t now = rd4(in);
+        const uint32_t h = hashOf(now);
+        Slot& slot = table[h];
+        const uint32_t diff = now ^ slot.seen;
+        const size_t cand = slot.pos;
+        slot.seen = now; slot.pos = (uint32_t)in;
+        bool usable = (diff & 0xffffffu) == 0 && cand != 0;
+        if (usable && !(in - cand > 2)) {
+            // a candidate 1 back is a run: taken only after >= 3 literals, when the 7 bytes from in-3 are all equal
+            usable = in == cand + 1 && literalsInARow >= 3 && in > 3;
+            for (size_t k = 1; usable && k <= 6; ++k) usable = src[in - 3 + k] == src[in - 3];
+        }
+        if (!usable) {
+            body[out++] = src[in++];
+            ctl >>= 1;
+            ++literalsInARow;
+            continue;
+        }
+        ctl = (ctl >> 1) | (1u << 31);
+        size_t len = 3;
+        if (diff == 0) {                                         // the 4th byte agrees too
+            len = 4;
+            if (src[cand + 4] == src[in + 4]) {
+                len = 5;
+                if (src[cand + 5] == src[in + 5]) {
+                    const size_t room = last - 4 - in + 1;       // never into the last 4 bytes
+                    const size_t cap = room > 255 ? 255 : room;
+                    len = 6;
+                    while (src[cand + len] == src[in + len] && len < cap) ++len;
+                }
+            }
+        }
+        if (len < 18) { const uint32_t w = (uint32_t)(len - 2) | (h << 4); body[out++] = (unsigned char)w; body[out++] = (unsigned char)(w >> 8); }
+        else { const uint32_t w = (uint32_t)(len << 16) | (h << 4); body[out++] = (unsigned char)w; body[out++] = (unsigned char)(w >> 8); body[out++] = (unsigned char)(w >> 16); }
+        in += len;
+        literalsInARow = 0;
+    }
+    if (!stored) {
+        while (in <= last) {                                     // the tail: literals; positions with 4 bytes left still refresh the table
+            flushIfFull();
+            if (in + 3 <= last) { const uint32_t now = rd4(in); Slot& slot = table[hashOf(now)]; slot.pos = (uint32_t)in; slot.seen = now; }
+            body[out++] = src[in++];
+            ctl >>= 1;
+        }
+        while ((ctl & 1u) == 0) ctl >>= 1;
+        putCtl((ctl >> 1) | (1u << 31));
+        if (out < 9) out = 9;                                    // upstream's minimum body length (the bytes past the data are unspecified there)
+    }
+    size_t total;
+    if (stored) { std::memcpy(body, src, size); total = head + size; }
+    else total = head + out;
+    dst[0] = (unsigned char)((1u << 6) | (1u << 2) | (head == 9 ? 2u : 0u) | (stored ? 0u : 1u));   // 01 SS=00 LL=01 H C
+    if (head == 3) { dst[1] = (unsigned char)total; dst[2] = (unsigned char)size; }
+    else for (int i = 0; i < 4; ++i) { dst[1 + i] = (unsigned char)((uint32_t)total >> (8 * i)); dst[5 + i] = (unsigned char)((uint32_t)size >> (8 * i)); }
+    return total;
+}
+
 void AssetManager_SetMeshCache(bool enabled) { g_cacheEnabled = enabled; }
 bool AssetManager_MeshCacheEnabled() { return g_cacheEnabled; }
 
@@ -124,8 +221,8 @@ bool AssetManager_SaveMeshToDisk(const char* path, const ObjMesh* mesh)
     const size_t bytes = (size_t)mesh->numTris * sizeof(Tri);
     if (mesh->numTris < 1000) ok = ok && (bytes == 0 || std::fwrite(mesh->tris, 1, bytes, f) == bytes);
     else {
-        std::vector<unsigned char> buf(bytes + 9);
-        const unsigned long long comp = MeshCache_QlzStore(reinterpret_cast<const unsigned char*>(mesh->tris), bytes, buf.data());
+        std::vector<unsigned char> buf(bytes + 400);             // AssetManager.cpp:312-314
+        const unsigned long long comp = MeshCache_QlzCompress(reinterpret_cast<const unsigned char*>(mesh->tris), bytes, buf.data());
         ok = ok && std::fwrite(&comp, 8, 1, f) == 1 && std::fwrite(buf.data(), 1, (size_t)comp, f) == (size_t)comp;
     }
     ok = (std::fclose(f) == 0) && ok;

@@ -53,6 +53,7 @@ size_t crth_jpeg_decode(const unsigned char* data, size_t size, unsigned char* d
 }
 void crth_set_asset_root(const char* dir) { ResourceManager::SetAssetRoot(dir); }
 size_t crth_qlz_store(const unsigned char* src, size_t size, unsigned char* dst) { return MeshCache_QlzStore(src, size, dst); }
+size_t crth_qlz_compress(const unsigned char* src, size_t size, unsigned char* dst) { return MeshCache_QlzCompress(src, size, dst); }
 void crth_set_device_bvh_build(int enabled) { ResourceManager::SetDeviceBVHBuild(enabled != 0); }
 void crth_push_textures(void) { ResourceManager::PushTexturesToGPU(); }
 void crth_push_materials(void) { ResourceManager::PushMaterialsToGPU(); }

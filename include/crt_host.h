@@ -31,6 +31,7 @@ void crth_set_device_bvh_build(int enabled);                 /* ResourceManager:
 void crth_set_mesh_cache(int enabled);                       /* AssetManager_SetMeshCache: the `.clm` cache (AssetManager.cpp:291-381), on by default */
 size_t crth_qlz_decompress(const unsigned char* src, size_t srcLen, unsigned char* dst, size_t dstCap); /* QuickLZ 1.5.0 level 1 */
 size_t crth_qlz_store(const unsigned char* src, size_t size, unsigned char* dst);                        /* stored block, size + 9 bytes */
+size_t crth_qlz_compress(const unsigned char* src, size_t size, unsigned char* dst);                     /* upstream's qlz_compress (level 1) byte for byte; dst: size + 400 bytes */
 /* JPEG -> RGB8 as the reference's stbi_load(path, &w, &h, &channels, 3) (ResourceManager.cpp:193). Returns the number of
  * bytes written (width*height*3), or 0 on failure (*error, if given, names the reason). With dst == NULL only the header is
  * read: info[0..3] = width, height, components in the file (1 or 3), progressive; the return value is the size needed. */

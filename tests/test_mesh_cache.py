@@ -111,7 +111,12 @@ def test_cache_written_on_import_and_preferred_afterwards(level, tmp_path):
     msz, = struct.unpack_from("<I", blob, 12 + 24 * nm)
     body = len(blob) - (12 + 24 * nm + 4 + msz)
     assert version == 0 and nt == len(first) and nm == 2
-    assert body == nt * 80 + (17 if nt >= 1000 else 0)                      # u64 size + 9-byte QuickLZ header only above the threshold
+    if nt < 1000:
+        assert body == nt * 80                                              # raw triangles below upstream's threshold
+    else:                                                                   # u64 size + the QuickLZ stream upstream's qlz_compress would write
+        comp, = struct.unpack_from("<Q", blob, len(blob) - body)
+        assert comp == body - 8 and comp < nt * 80 and blob[len(blob) - body + 8] == 0x47
+        assert blob[len(blob) - body + 8:] == qlz_compress(first.tobytes())
     os.utime(clm, (os.path.getmtime(obj) + 5, os.path.getmtime(obj) + 5))
     os.rename(obj, obj + ".hidden")                                          # only the cache can serve the import now
     with driver.Session(64, 48, host_only=True) as s:
@@ -186,3 +191,71 @@ def test_cache_with_a_lying_length_field_is_refused(tmp_path):
             s.h.crth_prepare_meshes()
             s.h.crth_import_mesh(str(tmp_path / "liar.obj").encode())
             assert s.h.crth_last_error() != 0 and s.h.crth_num_triangles() == 0
+
+
+def qlz_compress(raw):
+    H = _lib.host()
+    src = np.frombuffer(raw, np.uint8)
+    dst = np.zeros(len(raw) + 400, np.uint8)
+    n = H.crth_qlz_compress(src.ctypes.data, len(src), dst.ctypes.data)
+    return dst[:n].tobytes()
+
+
+@pytest.mark.parametrize("rel", FIXTURE_CLMS)
+def test_compressor_reproduces_the_streams_upstream_ships(rel):
+    """Golden vectors held by the reference itself: the QuickLZ streams inside its shipped .clm caches were written by
+    upstream's qlz_compress. Decode one, compress the triangles again with the product's compressor: the same bytes, so a
+    cache written here is the file upstream would have written. Needs no reference tree (the caches are data fixtures)."""
+    blob = open(os.path.join(FIXTURE_ASSETS, rel), "rb").read()
+    nt, at, comp = _clm_stream(blob)
+    stream = blob[at:at + comp]
+    n, tris = qlz_decompress(stream, nt * 80)
+    assert n == nt * 80
+    again = qlz_compress(tris.tobytes())
+    assert len(again) == comp and again == stream
+
+
+def _compressor_samples():
+    rng = np.random.RandomState(11)
+    runs = np.repeat(rng.randint(0, 256, 3000).astype(np.uint8), rng.randint(1, 300, 3000)).tobytes()
+    yield from [bytes(200000), b"abc" * 70000, (b"0123456789" * 10 + b"x") * 3000, runs,
+                rng.randint(0, 4, 150000).astype(np.uint8).tobytes(),            # low entropy
+                rng.randint(0, 256, 100000).astype(np.uint8).tobytes(),          # incompressible -> abandoned, stored block
+                rng.randint(0, 256, 50000).astype(np.uint8).tobytes() + bytes(50000),   # gives up or not at the half-way check
+                bytes(50000) + rng.randint(0, 256, 50000).astype(np.uint8).tobytes(),
+                bytes(range(256)) * 3, b"aaaaaaaaaaab" * 40, b"a" * 11, b"a" * 215, b"a" * 216, b"ab" * 108, b"abcdefghijk"]
+    for n in (11, 12, 17, 31, 64, 215, 216, 217, 1000, 4099, 65536):             # every size class incl. the short-header boundary
+        yield rng.randint(0, 3, n).astype(np.uint8).tobytes()
+        yield (rng.randint(0, 256, 7).astype(np.uint8).tobytes() * (n // 7 + 1))[:n]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libquicklz_ref.so is only built where the reference tree is mounted")
+def test_compressor_against_the_reference_codec():
+    """Byte-for-byte against the reference's qlz_compress (quicklz.c compiled as it lies) on repetitive, low-entropy, run-length,
+    incompressible and boundary-sized inputs, and on real triangle records."""
+    R = C.CDLL(REF_SO)
+    R.qlz_get_setting.restype = C.c_int
+    R.qlz_compress.restype = C.c_size_t
+    R.qlz_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    with driver.Session(64, 48, host_only=True) as s:
+        s.load_scene(scenes.get("tiny"))
+        tris = s.arenas()["tris"].copy()
+    kinds = set()
+    for raw in [tris.tobytes()] + list(_compressor_samples()):
+        state = C.create_string_buffer(R.qlz_get_setting(1))
+        comp = C.create_string_buffer(len(raw) + 400)
+        n = R.qlz_compress(raw, comp, len(raw), state)
+        mine = qlz_compress(raw)
+        assert len(mine) == n and mine == comp.raw[:n], (len(raw), n, len(mine))
+        kinds.add(mine[0])
+        got_n, got = qlz_decompress(mine, len(raw))
+        assert got_n == len(raw) and got.tobytes() == raw
+    assert kinds == {0x47, 0x46, 0x45, 0x44} or kinds >= {0x47, 0x46, 0x45}     # long/short header, compressed/stored
+
+
+def test_compressor_round_trips_without_the_reference():
+    for raw in _compressor_samples():
+        mine = qlz_compress(raw)
+        got_n, got = qlz_decompress(mine, len(raw))
+        assert got_n == len(raw) and got.tobytes() == raw, len(raw)
+    assert qlz_compress(b"") == b""
