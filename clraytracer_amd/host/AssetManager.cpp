@@ -188,7 +188,7 @@ static ObjMesh* AssetManager_ImportObj(const char* path, Tri* triArena, size_t m
     if (read_file(with_extension(path, "mtl"), mtl) && mtl.size() > 1) {
         mesh->mtlText = (char*)std::malloc(mtl.size());
         std::memcpy(mesh->mtlText, mtl.data(), mtl.size());
-        mesh->mtlSize = (unsigned)mtl.size();
+        mesh->mtlSize = (unsigned)mtl.size() - 1;               // the file's bytes, as upstream counts them (AssetManager.cpp:109,303); the buffer keeps a terminator behind them
         if (!parse_mtl(mesh, mtl.size() - 1, materialMap)) { AssetManager_DestroyMesh(mesh); return nullptr; }
     }
 

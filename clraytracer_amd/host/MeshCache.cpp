@@ -255,14 +255,14 @@ ObjMesh* AssetManager_LoadMeshFromDisk(const char* path, Tri* triArena, size_t m
     std::memset(mesh->materials, 0, sizeof mesh->materials);
     bool ok = take(mesh->materials, sizeof(ObjMaterial) * (size_t)numMaterials) && take(&msz, 4) && at + msz <= file.size();
     if (ok && msz) {
-        mesh->mtlText = (char*)std::malloc(msz);
+        mesh->mtlText = (char*)std::malloc((size_t)msz + 1);     // upstream stores the file's bytes without a terminator (AssetManager.cpp:303)
         mesh->mtlSize = msz;
         ok = take(mesh->mtlText, msz);
+        mesh->mtlText[msz] = '\0';
         for (int m = 0; ok && m < numMaterials; ++m) {            // offsets into mtlText must stay inside it
             const ObjMaterial& mt = mesh->materials[m];
             ok = (unsigned)mt.name < msz && (unsigned)mt.diffusePath < msz && (unsigned)mt.specularPath < msz;
         }
-        if (ok) mesh->mtlText[msz - 1] = '\0';
     } else if (ok && numMaterials) ok = false;
     const size_t bytes = (size_t)numTris * sizeof(Tri);
     if (ok && numTris < 1000) ok = take(triArena, bytes);

@@ -259,3 +259,34 @@ def test_compressor_round_trips_without_the_reference():
         got_n, got = qlz_decompress(mine, len(raw))
         assert got_n == len(raw) and got.tobytes() == raw, len(raw)
     assert qlz_compress(b"") == b""
+
+
+@pytest.mark.parametrize("rel", ["sphere.clm"] + FIXTURE_CLMS)
+def test_mtl_parser_reproduces_the_material_records_upstream_cached(rel, tmp_path, capfd):
+    """More golden data the reference holds: every shipped cache stores the `ObjMaterial` records upstream's importer parsed
+    out of the MTL file and the MTL text itself as the parser left it (a NUL written over the newline behind every name and
+    texture path; AssetManager.cpp:118-160,300-304). Put the newlines back, import a one-triangle OBJ that names that MTL
+    through the mirrored importer, and the cache written here must carry the same material records, the same text length
+    and the same terminated text, byte for byte: names, packed colours, half-float shininess / opacity, path offsets."""
+    import struct
+    blob = open(os.path.join(FIXTURE_ASSETS, rel), "rb").read()
+    version, nt, nm = struct.unpack_from("<Iii", blob, 0)
+    msz, = struct.unpack_from("<I", blob, 12 + 24 * nm)
+    text = bytearray(blob[16 + 24 * nm:16 + 24 * nm + msz])
+    assert nm >= 1 and text.count(0) >= nm
+    crlf = b"\r\n" in text                                                     # nanosuit's MTL was cached with CRLF line ends
+    for i in range(len(text)):
+        if text[i] == 0:
+            text[i] = 13 if (crlf and i + 1 < len(text) and text[i + 1] == 10) else 10
+    stem = os.path.splitext(os.path.basename(rel))[0]
+    (tmp_path / (stem + ".mtl")).write_bytes(bytes(text))
+    (tmp_path / (stem + ".obj")).write_text(f"mtllib {stem}.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\n")
+    with driver.Session(64, 48, host_only=True) as s:
+        s.h.crth_prepare_meshes()
+        s.h.crth_import_mesh(str(tmp_path / (stem + ".obj")).encode())           # textures are not there: those imports fall back, the mesh import stands
+    capfd.readouterr()
+    mine = (tmp_path / (stem + ".clm")).read_bytes()
+    head = 16 + 24 * nm + msz
+    assert struct.unpack_from("<Iii", mine, 0) == (0, 1, nm)
+    assert mine[8:head] == blob[8:head]                                          # numMaterials, ObjMaterial[], mtl size, mtl text
+    assert len(mine) == head + 80                                                # one raw triangle behind it
