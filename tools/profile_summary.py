@@ -83,7 +83,7 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
     with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
-        f.write(f"# rocprofv3 summary `{tag}` (MI355X, `python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline`)\n\n")
+        f.write(f"# rocprofv3 summary `{tag}` (MI355X, `python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-config5`)\n\n")
         if out["bench_line"]:
             b = out["bench_line"]
             f.write(f"bench line under the profiler: {b['value']} {b['unit']}, {b['ms_per_step']} ms/frame, workload `{b['config']['workload']}`\n\n")

@@ -6,8 +6,9 @@ set -o pipefail
 tag=${1:-r02}
 export TMPDIR=/tmp
 out=gpurun_out
-B="python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline"
-S="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+# --no-config5: the extra 3840x2160 point would launch the timed region's kernel at another size and blur its per-launch means
+B="python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-config5"
+S="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-config5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_stats -- $B > $out/prof_${tag}_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/prof_${tag}_fetch -- $S > $out/prof_${tag}_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/prof_${tag}_write -- $S > $out/prof_${tag}_write.log 2>&1 || exit 1
