@@ -19,3 +19,17 @@ with driver.Session(1920, 1080, device=0) as s:
         bad += h != g["frame_sha256"]
     print("soak: 60 rounds x ~51 frames,", bad, "mismatching hashes,", round(time.time() - t0, 1), "s")
     assert bad == 0
+    # the per-pixel stages mixed in (epilogue, FXAA ping-pong, RGBA8 read-back): every combination must keep giving the frame
+    # it gave the first time, and the plain frame must still be the golden one afterwards
+    combos = (1, 64, 1 | 64, 512, 512 | 1, 512 | 1 | 64, 1 | 64 | 128, 512 | 128)
+    first = {}
+    for round_ in range(12):
+        for f in combos:
+            for k in range(5):
+                hip.crt_render(*args, f | (4 if k else 0))
+            hsh = hashlib.sha256(s.read_output().tobytes()).hexdigest()
+            bad += first.setdefault(f, hsh) != hsh
+    hip.crt_render(*args, 0)
+    bad += hashlib.sha256(s.read_output().tobytes()).hexdigest() != g["frame_sha256"]
+    print("soak: 12 rounds x", len(combos), "stage combinations x 5 frames,", bad, "mismatches,", round(time.time() - t0, 1), "s")
+    assert bad == 0 and len(set(first.values())) >= 6
