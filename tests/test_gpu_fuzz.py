@@ -132,3 +132,33 @@ def test_pathological_scenes_extensions_and_device_build(tmp_path, nthreads, see
             assert a[k].tobytes() == b[k].tobytes(), k
         s.render_raw(0)
         assert np.array_equal(bits(s.read_output()), bits(plain))
+
+
+@pytest.mark.parametrize("seed,sizes,grid,kinds", [CASES[2], CASES[3], CASES[4]], ids=["seed3", "seed4", "seed5"])
+def test_pathological_instances_through_the_instance_tree(tmp_path, nthreads, monkeypatch, seed, sizes, grid, kinds):
+    """CRT_TLAS=1 forces the instance tree (normally used above 64 instances) onto the scenes whose instance matrices are
+    singular, tiny or huge: bounds that are degenerate, Inf or NaN must never hide an instance the linear loop would visit.
+    Plus 90 more instances of every kind, so the tree has real depth."""
+    monkeypatch.setenv("CRT_TLAS", "1")
+    rng = np.random.default_rng(seed)
+    sc = build_scene(tmp_path, rng, seed, sizes, grid, kinds)
+    all_kinds = ["plain", "mirrored", "tiny", "huge", "flat", "zero"]
+    for k in range(90):
+        sc.instances.append(scenes.Instance(k % len(sizes), 0xFFFF, matrices(rng, all_kinds[k % len(all_kinds)])))
+    with np.errstate(all="ignore"), driver.Session(208, 120, device=0) as s:
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        o, d = special_rays(rng, 8192)
+        got = s.query_hits(o, d)
+        cnt = s.counters()
+        ref, st = orc.closest_hits(o, d)
+        assert got.tobytes() == ref.tobytes() and cnt == st
+        s.render_raw(8)
+        iv, ip, pos = s.camera()
+        want, fst = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
+        assert s.counters() == fst
+        assert ((bits(s.read_output()) != bits(want)).any(axis=2)).sum() <= 2
+        s.render_raw(8 | 32)
+        want, fst = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle, shadows=True)
+        assert s.counters() == fst
+        assert ((bits(s.read_output()) != bits(want)).any(axis=2)).sum() <= 2
