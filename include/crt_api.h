@@ -46,17 +46,17 @@ enum {
                                      hit towards the sun sets the `shadow` factor of kernel_main.cl:264; see DESIGN.md */
     CRT_RENDER_UNORM8      = 64,  /* hazard H8: upstream renders into an RGBA8-UNORM texture (Renderer.cpp:63,192): quantise the
                                      Trace result like write_imagef/read_imagef before PostProcess and the final frame after it */
+    CRT_RENDER_READBACK    = 128, /* also copy the finished frame to pinned host memory behind its kernels (float4, or RGBA8 bytes
+                                     with CRT_RENDER_UNORM8); fetch it with crt_map_host_frame. Overlaps with the other frames in flight */
     CRT_RENDER_REFRACTION  = 256, /* extension (upstream README TODO "refraction / transculency", no upstream code): at the first hit
                                      of a material whose MTL `d` (opacity, Material::roughness) is below 1 the bounce ray is the
                                      refracted ray (index 1.5) with (1 - opacity) of the energy; defined by the oracle, see DESIGN.md */
-    CRT_RENDER_FXAA        = 512, /* extension: upstream's FXAA function (kernel_main.cl:289-340) is dead code -- its call is commented out
+    CRT_RENDER_FXAA        = 512  /* extension: upstream's FXAA function (kernel_main.cl:289-340) is dead code -- its call is commented out
                                      (kernel_main.cl:349), it returns nothing and would read pixels PostProcess is rewriting. Run it
                                      as the first PostProcess stage (or alone, without CRT_RENDER_POSTPROCESS), reading the unmodified
                                      Trace result; semantics defined by the oracle (orc_fxaa). Whole frames only: refused while
                                      crt_set_row_bands leaves this device a share of the rows (an in-process multi-GPU session
                                      gathers first and filters on its first device) */
-    CRT_RENDER_READBACK    = 128  /* also copy the finished frame to pinned host memory behind its kernels (float4, or RGBA8 bytes
-                                     with CRT_RENDER_UNORM8); fetch it with crt_map_host_frame. Overlaps with the other frames in flight */
 };
 
 /* Device work counters of the last CRT_RENDER_COUNTERS / crt_query_hits launch. Same meaning as
