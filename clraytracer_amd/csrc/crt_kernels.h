@@ -92,7 +92,29 @@ __device__ __forceinline__ bool lane_pixel(const CrtFrame& F, int& px, int& py, 
 // chain, not the throughput, decide when the frame ends. (A fixed "more than half the maximum, at most 96" rule
 // over-split large frames: 1920x1080 ran 16 % slower with 96 than with 4 splits per XCD, while one rank's eighth of
 // a 3840x2160 frame wanted them.) At most maxSplit tiles per XCD; they come first in the list.
-__global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
+// Sort key of a tile = its own cost or `spread` x the heaviest of its eight neighbours' costs, whichever is larger: when the
+// camera moves, the heavy tiles of the next frame are the heavy tiles of this one or the tiles next to them.
+__global__ void crt_cost_spread_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ key, int slotsPerXcd, int tilesX, float spread)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 8 * slotsPerXcd) return;
+    const int x = g / slotsPerXcd, i = g - x * slotsPerXcd;
+    const int round = i / tilesX, tx = i - round * tilesX;
+    const int k = round * 8 + x, rows = (slotsPerXcd / tilesX) * 8;
+    uint32_t nb = 0;
+    for (int dk = -1; dk <= 1; ++dk)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int kk = k + dk, xx = tx + dx;
+            if ((dk | dx) == 0 || kk < 0 || kk >= rows || xx < 0 || xx >= tilesX) continue;
+            const uint32_t c = cost[(size_t)(kk & 7) * slotsPerXcd + (size_t)(kk >> 3) * tilesX + xx];
+            nb = c > nb ? c : nb;
+        }
+    const uint32_t own = cost[g], lifted = (uint32_t)((float)nb * spread);
+    key[g] = own > lifted ? own : lifted;
+}
+
+// `key`: what the tiles are sorted and split by (crt_cost_spread_kernel's output, or the costs themselves)
+__global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ cost, const uint32_t* __restrict__ key, uint32_t* __restrict__ order,
                                                        uint32_t* __restrict__ listLen, int slotsPerXcd, int listCap, uint32_t maxSplit,
                                                        float splitFactor)
 {
@@ -100,13 +122,14 @@ __global__ __launch_bounds__(1024) void crt_order_kernel(uint32_t* __restrict__ 
     __shared__ uint32_t s_max, s_nSplit;
     __shared__ float s_sum;
     const int x = blockIdx.x, tid = threadIdx.x;
-    const uint32_t* c = cost + (size_t)x * slotsPerXcd;
+    const uint32_t* c = key + (size_t)x * slotsPerXcd;
+    const uint32_t* own = cost + (size_t)x * slotsPerXcd;
     uint32_t* o = order + (size_t)x * listCap;
     s_bins[tid] = 0;
     if (tid == 0) { s_max = 1; s_sum = 0.0f; }
     __syncthreads();
     uint32_t m = 0; float sum = 0.0f;
-    for (int i = tid; i < slotsPerXcd; i += 1024) { m = c[i] > m ? c[i] : m; sum += (float)c[i]; }
+    for (int i = tid; i < slotsPerXcd; i += 1024) { m = c[i] > m ? c[i] : m; sum += (float)own[i]; }
     atomicMax(&s_max, m);
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if ((tid & 63) == 0) atomicAdd(&s_sum, sum);

@@ -94,6 +94,10 @@ struct State {
     uint32_t smallPacket = CRT_SMALL_PACKET, smallPacketAsync = CRT_SMALL_PACKET_ASYNC;   // CrtFrame::smallPacket for synchronous / pipelined frames
     int forceTlas = -1;   // CRT_TLAS=0/1: force the linear / tree candidate search (tests); default: by instance count
     int feedbackAsync = 0; int feedback = 1; int maxSplit = CRT_MAX_SPLIT, maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED;
+    // feedback lists while the view changes: rank a tile by max(own cost, costSpread x heaviest of its 8 neighbours) -- next
+    // frame's heavy tiles are this frame's or the ones next to them. A view that stood still for a frame is ranked by own cost.
+    float costSpread = 0.8f;
+    float lastView[35] = { 0 }; unsigned long long lastViewInst = 0; bool viewMoved = false;   // camera matrices + position / instance version of the last sorted frame
     float splitBeta = CRT_SPLIT_BETA, splitBetaAsync = CRT_SPLIT_BETA_ASYNC;   // split a tile whose wave would run longer than beta x the XCD's time for the frame
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
@@ -547,6 +551,7 @@ static int init_impl(int device, int width, int height)
     { const char* e = getenv("CRT_SMALL_PACKET_ASYNC"); g.smallPacketAsync = e ? (uint32_t)atoi(e) : (uint32_t)CRT_SMALL_PACKET_ASYNC; }
     { const char* e = getenv("CRT_SPLIT_BETA"); g.splitBeta = e ? (float)atof(e) : CRT_SPLIT_BETA; }
     { const char* e = getenv("CRT_SPLIT_BETA_ASYNC"); g.splitBetaAsync = e ? (float)atof(e) : CRT_SPLIT_BETA_ASYNC; }
+    { const char* e = getenv("CRT_COST_SPREAD"); g.costSpread = e ? (float)atof(e) : 0.8f; }
     { const char* e = getenv("CRT_SPLIT");               // tuning knob: cap on quadrant-split tiles per XCD (both modes)
       if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
       else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
@@ -884,6 +889,19 @@ int crt1_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count)
 // lists (and the costs zeroed) by a sort that is queued right AFTER the previous frame's last kernel and its end
 // event (sort_for_next_frame), so it runs while the host is between two crt1_render calls and is off the frame's
 // critical path (it used to open every frame: 10 us + a launch gap of a 0.5 ms synchronous frame).
+// this frame's per-tile costs -> the next frame's lists; with g.costSpread > 0 a tile is ranked by its neighbours' costs too
+static void launch_order_kernel(const CrtFrame& F, FrameSlot& fs, bool pipelined)
+{
+    const uint32_t* key = fs.cost;
+    if (g.costSpread > 0.0f && g.viewMoved) {
+        uint32_t* k2 = fs.cost + fs.orderCap;                   // second half of the cost allocation
+        crt_cost_spread_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, fs.stream>>>(fs.cost, k2, F.slotsPerXcd, F.tilesX, g.costSpread);
+        key = k2;
+    }
+    crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, key, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit),
+                                                 (pipelined ? g.splitBetaAsync : g.splitBeta) / (float)((g.numCUs / 8) * 4 * CRT_WAVES_PER_SIMD));
+}
+
 static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool pipelined)
 {
     const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
@@ -896,7 +914,7 @@ static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool
         fs.order = nullptr; fs.len = nullptr; fs.cost = nullptr; fs.orderCap = 0;
         HIPCHK(hipMalloc(&fs.order, sizeof(uint32_t) * need));
         HIPCHK(hipMalloc(&fs.len, sizeof(uint32_t) * 8));
-        HIPCHK(hipMalloc(&fs.cost, sizeof(uint32_t) * need));
+        HIPCHK(hipMalloc(&fs.cost, sizeof(uint32_t) * need * 2));        // costs, then the sort keys derived from them
         fs.orderCap = need; fs.orderSlots = -1;
     }
     if (fs.orderSlots != F.slotsPerXcd || memcmp(key, fs.orderKey, sizeof key) != 0) {
@@ -904,8 +922,7 @@ static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool
         crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, fs.stream>>>(fs.order, fs.len, F.slotsPerXcd, F.listCap);
         fs.orderSlots = F.slotsPerXcd; memcpy(fs.orderKey, key, sizeof key);
     } else if (!fs.listsReady) {
-        crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit),
-                                                     (pipelined ? g.splitBetaAsync : g.splitBeta) / (float)((g.numCUs / 8) * 4 * CRT_WAVES_PER_SIMD));
+        launch_order_kernel(F, fs, pipelined);
     }
     fs.listsReady = false;
     HIPCHK(hipGetLastError());
@@ -918,8 +935,7 @@ static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool
 // caught by the key in prepare_launch_lists, which then starts from the identity order again).
 static int sort_for_next_frame(const CrtFrame& F, FrameSlot& fs, bool pipelined)
 {
-    crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, fs.order, fs.len, F.slotsPerXcd, F.listCap, (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit),
-                                                 (pipelined ? g.splitBetaAsync : g.splitBeta) / (float)((g.numCUs / 8) * 4 * CRT_WAVES_PER_SIMD));
+    launch_order_kernel(F, fs, pipelined);
     HIPCHK(hipGetLastError());
     fs.listsReady = true;
     return CRT_OK;
@@ -1122,7 +1138,14 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     g.cur = slot;
     es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
     const bool sorted = F.order != nullptr;
-    if (sorted) { rc = sort_for_next_frame(F, fs, pipelined); if (rc) return rc; }
+    if (sorted) {
+        // did the view change since the last sorted frame? (camera matrices and position, instance tables)
+        float view[35];
+        memcpy(view, F.invView, 64); memcpy(view + 16, F.invProj, 64); memcpy(view + 32, F.camPos, 12);
+        g.viewMoved = memcmp(view, g.lastView, sizeof view) != 0 || g.lastViewInst != g.instVersion;
+        memcpy(g.lastView, view, sizeof view); g.lastViewInst = g.instVersion;
+        rc = sort_for_next_frame(F, fs, pipelined); if (rc) return rc;
+    }
     if (flags & CRT_RENDER_READBACK) {
         // the frame travels to pinned host memory behind its own kernels; the other slots' frames keep the GPU busy meanwhile
         const size_t pixels = (size_t)g.width * (size_t)g.height;
