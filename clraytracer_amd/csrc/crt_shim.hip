@@ -960,6 +960,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         g.stampWaves = grid;
         HIPCHK(hipMemsetAsync(g.stamps, 0, need, fs.stream));
         crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps);
+        *epilogueApplied = true;                           // the same kernel template: F.epilogue is applied there
     } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
         const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
         const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;

@@ -66,3 +66,24 @@ def test_straggler_hand_off_is_bit_identical(name, monkeypatch):
         s.load_scene(sc)
         s.render_raw(256)
         assert np.array_equal(bits(s.read_output()), bits(with_refraction))
+
+
+def test_stamped_launch_renders_the_same_frame():
+    """CRT_RENDER_STAMPS (the diagnostic instantiation behind tools/wave_timeline.py: per-wave start/end stamps, 6 waves per
+    SIMD) must render the frame the plain launch renders -- also through the per-pixel epilogue (PostProcess, RGBA8 target),
+    which the stamped instantiation applies itself -- and hand back one sane stamp record per wave."""
+    import ctypes as C
+    sc = scenes.get("tiny")
+    STAMPS, POST, UNORM8 = 16, 1, 64
+    with driver.Session(256, 144, device=0) as s:
+        s.load_scene(sc)
+        for extra in (0, POST, POST | UNORM8):
+            s.render_raw(extra); want = s.read_output().copy()
+            s.render_raw(STAMPS | extra)
+            assert np.array_equal(bits(s.read_output()), bits(want)), extra
+        n = C.c_size_t(0)
+        assert s.hip.crt_debug_read_stamps(None, 0, C.byref(n)) == 0 and n.value >= (256 // 8) * (144 // 8)
+        st = np.zeros((n.value, 8), np.uint64)
+        assert s.hip.crt_debug_read_stamps(st.ctypes.data, n.value, C.byref(n)) == 0
+        ran = st[st[:, 1] > 0]                                # waves of the list padding never start
+        assert len(ran) >= (256 // 8) * (144 // 8) and (ran[:, 1] >= ran[:, 0]).all() and (ran[:, 2] > 0).all()
