@@ -290,3 +290,33 @@ def test_mtl_parser_reproduces_the_material_records_upstream_cached(rel, tmp_pat
     assert struct.unpack_from("<Iii", mine, 0) == (0, 1, nm)
     assert mine[8:head] == blob[8:head]                                          # numMaterials, ObjMaterial[], mtl size, mtl text
     assert len(mine) == head + 80                                                # one raw triangle behind it
+
+
+def test_decoder_survives_damaged_streams():
+    """2000 seeded mutations (bit flips, truncations, spliced garbage, lying size fields) of valid streams: the decoder returns
+    a length or 0 and never reads or writes outside its buffers (run under ASan + UBSan by tools/sanitize_host.sh)."""
+    rng = np.random.RandomState(5)
+    valid = [qlz_compress(raw) for raw in list(_compressor_samples())[:12]]
+    sizes = [len(raw) for raw in list(_compressor_samples())[:12]]
+    ok = 0
+    for k in range(2000):
+        i = int(rng.randint(len(valid)))
+        b = bytearray(valid[i])
+        kind = k % 5
+        if kind == 0:
+            for _ in range(int(rng.randint(1, 6))):
+                b[int(rng.randint(len(b)))] ^= 1 << int(rng.randint(8))
+        elif kind == 1:
+            b = b[:int(rng.randint(0, len(b)))]
+        elif kind == 2:
+            at = int(rng.randint(len(b)))
+            b[at:at + 8] = rng.randint(0, 256, 8).astype(np.uint8).tobytes()
+        elif kind == 3 and len(b) > 9:
+            b[1:9] = rng.randint(0, 256, 8).astype(np.uint8).tobytes()      # compressed / decompressed size fields
+        else:
+            b = bytearray(rng.randint(0, 256, int(rng.randint(1, 64))).astype(np.uint8).tobytes())
+        cap = sizes[i] if k % 3 else int(rng.randint(0, sizes[i] + 1))        # also output buffers that are too small
+        n, out = qlz_decompress(bytes(b), cap)
+        assert n == 0 or n <= cap
+        ok += n != 0
+    assert ok < 2000
