@@ -179,3 +179,64 @@ def test_triangle_arena_capacity_is_an_error_not_an_overrun(tmp_path):
         h.crth_import_mesh(obj.encode())
         assert h.crth_last_error() in (-2, -3) and h.crth_num_meshes() == 3
         h.crth_set_mesh_cache(1)
+
+
+def test_importer_survives_damaged_files(quad, tmp_path, capfd):
+    """600 seeded mutations of a valid OBJ / MTL / .clm triple (byte flips, truncations, inserted garbage, huge indices and
+    counts): every import returns a mesh or an error code -- nothing exits, hangs, or touches memory outside its buffers
+    (run under ASan + UBSan by tools/sanitize_host.sh). Upstream's parser trusts its input; this one is a file-facing
+    boundary."""
+    import os
+    import shutil
+    rng = np.random.RandomState(9)
+    obj = (quad / "quad.obj").read_bytes(); mtl = (quad / "quad.mtl").read_bytes()
+    # a valid cache of the same mesh, written by the importer itself
+    with driver.Session(64, 48, host_only=True):
+        H.crth_prepare_meshes()
+        assert H.crth_import_mesh(str(quad / "quad.obj").encode()) == 0
+    clm = (quad / "quad.clm").read_bytes()
+
+    def mutate(b):
+        b = bytearray(b)
+        kind = int(rng.randint(6))
+        if kind == 0 and len(b):
+            for _ in range(int(rng.randint(1, 8))):
+                b[int(rng.randint(len(b)))] = int(rng.randint(256))
+        elif kind == 1:
+            b = b[:int(rng.randint(0, len(b) + 1))]
+        elif kind == 2:
+            at = int(rng.randint(len(b) + 1)); b[at:at] = rng.randint(0, 256, int(rng.randint(1, 40))).astype(np.uint8).tobytes()
+        elif kind == 3:
+            at = int(rng.randint(len(b) + 1)); b[at:at] = rng.choice([b"f 99999999/1/1 2/2/2 3/3/3\n", b"f -5/-5/-5 1/1/1 2/2/2\n", b"v 1e39 nan inf\n", b"usemtl nosuch\n",
+                                                                     b"newmtl " + b"x" * 300 + b"\n", b"map_Kd " + b"y" * 600 + b"\n", b"f 1 2 3\n", b"f 1//1 2//2 3//3 4//4 5//5\n"])
+        elif kind == 4:
+            b = b.replace(b"\n", b"\r\n")
+        else:
+            b = b.replace(b" ", b"\t", int(rng.randint(1, 5)))
+        return bytes(b)
+
+    outcomes = {"ok": 0, "error": 0}
+    for k in range(600):
+        d = tmp_path / f"m{k % 7}"
+        shutil.rmtree(d, ignore_errors=True); d.mkdir()
+        which = k % 3
+        (d / "quad.obj").write_bytes(mutate(obj) if which == 0 else obj)
+        (d / "quad.mtl").write_bytes(mutate(mtl) if which == 1 else mtl)
+        shutil.copy(quad / "tex.ppm", d / "tex.ppm")
+        if which == 2:                                          # a damaged cache that looks fresher than the OBJ
+            (d / "quad.clm").write_bytes(mutate(clm))
+            t = os.path.getmtime(d / "quad.obj") + 5
+            os.utime(d / "quad.clm", (t, t))
+            if k % 2:
+                os.remove(d / "quad.obj")                       # ... with or without the OBJ to fall back to
+        with driver.Session(64, 48, host_only=True):
+            H.crth_prepare_meshes()
+            h = H.crth_import_mesh(str(d / "quad.obj").encode())
+            err = H.crth_last_error()
+            assert (err == 0) or (err < 0)
+            outcomes["ok" if err == 0 else "error"] += 1
+            if err == 0:
+                info = np.zeros(4, np.uint32); H.crth_mesh_info(h, info.ctypes.data)
+                assert info[0] <= 100000                        # whatever was parsed is bounded by the file
+    capfd.readouterr()
+    assert outcomes["ok"] > 50 and outcomes["error"] > 50, outcomes
