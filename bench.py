@@ -355,28 +355,34 @@ def main():
     # frame's kernels (CRT_RENDER_READBACK moves only the rows a rank owns), the last copy complete before the clock
     # stops. The headline above leaves the tiles in each rank's HBM; this is the rate at which a whole frame reaches
     # one place (host memory of the node) that a consumer can read.
-    deliver_elapsed = None
+    deliver_elapsed = deliver8_elapsed = None
     if n > 1 and not inproc:
-        dflags = flags | 128
-        ptr, nbytes = C.c_void_p(), C.c_size_t()
-        for _ in range(min(args.warmup, 3)):
-            _lib.check(crt_render(p_args, p_iv, p_ip, dflags), "crt_render")
-        _lib.check(hip.crt_map_host_frame(C.byref(ptr), C.byref(nbytes)), "crt_map_host_frame")
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            rc = crt_render(p_args, p_iv, p_ip, dflags)
-        rc2 = hip.crt_map_host_frame(C.byref(ptr), C.byref(nbytes))      # waits for the last frame's copy
-        rc3 = hip.crt_sync()
-        barrier()
-        deliver_elapsed = time.perf_counter() - t0
-        _lib.check(rc, "crt_render"); _lib.check(rc2, "crt_map_host_frame"); _lib.check(rc3, "crt_sync")
+        def delivered(dflags):
+            ptr, nbytes = C.c_void_p(), C.c_size_t()
+            for _ in range(min(args.warmup, 3)):
+                _lib.check(crt_render(p_args, p_iv, p_ip, dflags), "crt_render")
+            _lib.check(hip.crt_map_host_frame(C.byref(ptr), C.byref(nbytes)), "crt_map_host_frame")
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rc = crt_render(p_args, p_iv, p_ip, dflags)
+            rc2 = hip.crt_map_host_frame(C.byref(ptr), C.byref(nbytes))      # waits for the last frame's copy
+            rc3 = hip.crt_sync()
+            barrier()
+            dt = time.perf_counter() - t0
+            _lib.check(rc, "crt_render"); _lib.check(rc2, "crt_map_host_frame"); _lib.check(rc3, "crt_sync")
+            return dt
+        deliver_elapsed = delivered(flags | 128)                             # float4 HDR: 16 B per pixel over each rank's PCIe link
+        # ... and as what upstream displays: the frame through its RGBA8 render target (CRT_RENDER_UNORM8: the pixels are
+        # quantised, hazard H8), 4 B per pixel
+        deliver8_elapsed = delivered(flags | 128 | 64)
 
     tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, extent_ms, red_device, ctl)
     if sync_elapsed is not None:
         _, sync_elapsed, _ = aggregate(dist, cnt, own_rows * width, sync_elapsed, 0.0, red_device, ctl)
     if deliver_elapsed is not None:
         _, deliver_elapsed, _ = aggregate(dist, cnt, own_rows * width, deliver_elapsed, 0.0, red_device, ctl)
+        _, deliver8_elapsed, _ = aggregate(dist, cnt, own_rows * width, deliver8_elapsed, 0.0, red_device, ctl)
 
     if rank == 0:
         rays_per_frame = tot["rays"]
@@ -447,6 +453,9 @@ def main():
             out["delivered_to_host"] = {"value": round(rays_per_frame * args.steps / deliver_elapsed / 1e6, 2), "unit": "Mrays/s",
                                         "ms_per_step": round(deliver_elapsed * 1e3 / args.steps, 4),
                                         "note": "same K frames, every rank's bands copied to pinned host memory per frame inside the timed region (float4), max over ranks"}
+            out["delivered_to_host_rgba8"] = {"value": round(rays_per_frame * args.steps / deliver8_elapsed / 1e6, 2), "unit": "Mrays/s",
+                                              "ms_per_step": round(deliver8_elapsed * 1e3 / args.steps, 4),
+                                              "note": "the same with the frame taken through upstream's RGBA8 render target (CRT_RENDER_UNORM8): 4 B per pixel instead of 16"}
         if single is not None:
             out["single_gpu_same_workload"] = {"value": round(rays_per_frame / single / 1e6, 2), "unit": "Mrays/s",
                                                "ms_per_step": round(single * 1e3, 4), "note": "rank 0 alone rendering the whole frame, 10 frames, same mode"}
