@@ -139,6 +139,7 @@ struct CrtFrame {
     uint32_t suspendAt;       // straggler hand-off (crt_trace_fast_kernel): suspend the remaining lanes once this few still work; 0 = never
     uint32_t suspendAfter;    // ... and only in waves that have run at least this many trips in the current bounce
     uint32_t epilogue;        // crt_trace_kernel: per-pixel stages applied before the pixel is stored (CRT_EPILOGUE_*); 0 = the plain HDR value
+    uint32_t* packOut;        // with CRT_EPILOGUE_QUANTIZE: also store the pixel's RGBA8 bytes here (the frame a read-back delivers); or null
 };
 
 struct v3 { float x, y, z; };

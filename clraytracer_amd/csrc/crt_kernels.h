@@ -289,6 +289,8 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
             if (F.epilogue & CRT_EPILOGUE_QUANTIZE) rgb = mk3(quantize1(rgb.x), quantize1(rgb.y), quantize1(rgb.z));
         }
         out[(size_t)qy * (size_t)F.width + (size_t)qx] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+        // the bytes of upstream's RGBA8 texture, for a read-back (what crt_pack_unorm8_kernel would make of the value just stored)
+        if (F.packOut) F.packOut[(size_t)qy * (size_t)F.width + (size_t)qx] = unorm8(rgb.x) | (unorm8(rgb.y) << 8) | (unorm8(rgb.z) << 16) | 0xFF000000u;
     }
     if (F.cost && costSlot >= 0) {      // per-tile cost of this frame (wave-uniform value, one store)
         // the four quadrant waves of a split tile each add half their cycles: about what the tile would take as one wave
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(CRT_BLOCK) void crt_fxaa_kernel(CrtFrame F, const f
     if (F.epilogue & CRT_EPILOGUE_POST) o = post_pixel(o, px, py, W, H);
     if (F.epilogue & CRT_EPILOGUE_QUANTIZE) o = mk3(quantize1(o.x), quantize1(o.y), quantize1(o.z));
     dst[(size_t)py * (size_t)W + (size_t)px] = make_float4(o.x, o.y, o.z, 1.0f);
+    if (F.packOut) F.packOut[(size_t)py * (size_t)W + (size_t)px] = unorm8(o.x) | (unorm8(o.y) << 8) | (unorm8(o.z) << 16) | 0xFF000000u;
 }
 
 // Hazard H8: the store + load through upstream's RGBA8-UNORM render target (write_imagef / read_imagef):

@@ -1082,6 +1082,17 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     }
     if (!fxaa) F.epilogue = (unorm ? CRT_EPILOGUE_QUANTIZE : 0u) | (post ? CRT_EPILOGUE_POST : 0u);
     else if (fxaaLocal) F.epilogue = unorm ? CRT_EPILOGUE_QUANTIZE : 0u;
+    // a read-back of the RGBA8 frame: the kernel that stores the final pixel stores its four bytes too (one device; a
+    // multi-device session packs the gathered frame on its first device)
+    const bool packInKernel = unorm && (flags & CRT_RENDER_READBACK) && g.groupSize <= 1;
+    if (packInKernel && framePixels * 4 > fs.packCap) {
+        HIPCHK(hipStreamSynchronize(fs.stream));
+        if (fs.packBuf) (void)hipFree(fs.packBuf);
+        fs.packBuf = nullptr; fs.packCap = 0;
+        HIPCHK(hipMalloc(&fs.packBuf, framePixels * 4));
+        fs.packCap = framePixels * 4;
+    }
+    if (packInKernel && !fxaa) F.packOut = fs.packBuf;
     bool fused = false;
     rc = launch_trace(S, F, flags, grid, fs, fxaaLocal ? fs.aux : fs.out, &fused);
     if (rc) return rc;
@@ -1123,6 +1134,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
                 HIPCHK(hipMemcpyAsync(fs.aux, fs.out, framePixels * sizeof(float4), hipMemcpyDeviceToDevice, fs.stream));
             }
             FF.epilogue = (unorm ? CRT_EPILOGUE_QUANTIZE : 0u) | (post ? CRT_EPILOGUE_POST : 0u);
+            FF.packOut = packInKernel ? fs.packBuf : nullptr;
             crt_fxaa_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.aux, fs.out);
             HIPCHK(hipGetLastError());
         }
@@ -1167,7 +1179,8 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
                 HIPCHK(hipMalloc(&fs.packBuf, pixels * 4));
                 fs.packCap = pixels * 4;
             }
-            crt_pack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, fs.stream>>>(fs.out, fs.packBuf, pixels);
+            const bool packed = packInKernel && (fxaa || fused);     // the Trace (or FXAA) kernel stored the bytes already
+            if (!packed) crt_pack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, fs.stream>>>(fs.out, fs.packBuf, pixels);
             HIPCHK(hipGetLastError());
             src = fs.packBuf;
         }
