@@ -30,5 +30,7 @@ with driver.Session(W, H, device=0) as s:
 
     print(f"{name} {W}x{H}                       in flight   synchronous")
     for label, f in (("Trace only (float4 HDR)", 0), ("+ PostProcess", 1), ("+ RGBA8 target + PostProcess (upstream's Render)", 1 | 64),
-                     ("+ FXAA + PostProcess", 1 | 512), ("+ RGBA8 + FXAA + PostProcess", 1 | 64 | 512)):
-        print(f"  {label:50s} {ms(f | 4):.4f} ms   {ms(f):.4f} ms", flush=True)
+                     ("+ RGBA8 + PostProcess, bytes delivered to host memory", 1 | 64 | 128),
+                     ("+ FXAA + PostProcess", 1 | 512), ("+ RGBA8 + FXAA + PostProcess", 1 | 64 | 512),
+                     ("+ RGBA8 + FXAA + PostProcess, bytes delivered to host memory", 1 | 64 | 512 | 128)):
+        print(f"  {label:62s} {ms(f | 4):.4f} ms   {ms(f):.4f} ms", flush=True)
