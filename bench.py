@@ -33,8 +33,9 @@ The JSON line also carries
                  hot data sits in L1/L2/Infinity Cache), so their rate is not a fraction of any roofline.
                  `gather`: real (post-cull) 64-B child-pair fetches per cycle per CU against the vector-memory pipeline's
                  ceiling for such fetches (tools/ubench/gather.hip), with the fully-divergent-from-L2 rate as a reference
-                 point; `valu`: VALU issue occupancy and lane utilisation from the committed SQ PMC passes -- the
-                 resource this kernel is closest to saturating.
+                 point; `valu`: VALU issue occupancy (2 cycles per wave64 instruction on a SIMD-32), lane utilisation and L1
+                 line accesses per cycle from the committed PMC passes: no unit is saturated -- the kernel waits on
+                 dependent gathers.
   cpu_baseline : the reference's CPU path timed on this box's host cores (rank 0, N == 1 only): the mirrored
                  CPU_RayCast (CPURayTrace.cpp:186-249, SSE flavour with upstream's rcpps/dpps instruction mix) over the
                  primary rays of the bench frame at 1 thread and at all usable cores, and the scalar Trace oracle
@@ -109,9 +110,10 @@ def aggregate(dist, cnt, own_pixels, elapsed_s, kernel_ms_mean, device, group=No
     return tot, tmax[0].item(), tmax[1].item()
 
 
-def pmc_valu(kernel, workload_scene, width, height):
-    """VALU issue-slot occupancy and lane utilisation of the dominant kernel from the committed SQ PMC passes
-    (profiles/*_summary.json `derived`), or None."""
+def pmc_valu(kernel, workload_scene, width, height, dev_s, clock_ghz, num_cus):
+    """Issue-side accounting of the dominant kernel from the committed PMC passes (profiles/*_summary.json): VALU
+    instructions and L1 line accesses per launch are properties of the work, so they are put over THIS run's device time per
+    launch; the fractions measured inside the (serialised, slower) profiled launch are passed through as they are."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
         try:
@@ -119,11 +121,21 @@ def pmc_valu(kernel, workload_scene, width, height):
             b = d.get("bench_line") or {}
             dv = d.get("derived", {})
             if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene \
-                    and b["config"].get("width") == width and b["config"].get("height") == height and "valu_issue_busy" in dv:
-                return {"issue_busy": round(dv["valu_issue_busy"], 3), "lane_utilisation": round(dv["valu_lane_utilisation"], 3),
-                        "source": os.path.relpath(path, ROOT),
-                        "note": "SQ_ACTIVE_INST_VALU / (SIMDs x busy quad-cycles) and SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): "
-                                "the resource this kernel is closest to saturating"}
+                    and b["config"].get("width") == width and b["config"].get("height") == height and "valu_insts_per_launch" in dv:
+                cyc = dev_s * clock_ghz * 1e9                     # cycles of device time per launch in this run
+                out = {"issue_busy": round(dv["valu_insts_per_launch"] * 2.0 / (4.0 * num_cus * cyc), 3),
+                       "issue_busy_profiled_launch": round(dv["valu_issue_busy"], 3),
+                       "lane_utilisation": round(dv["valu_lane_utilisation"], 3),
+                       "source": os.path.relpath(path, ROOT),
+                       "note": "issue_busy = SQ_INSTS_VALU x 2 cycles (a wave64 instruction on a SIMD-32) / (SIMDs x this run's device cycles "
+                               "per launch at the nominal clock); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"}
+                if "l1_line_accesses_per_launch" in dv:
+                    out["l1_line_accesses_per_cycle_per_cu"] = round(dv["l1_line_accesses_per_launch"] / (num_cus * cyc), 3)
+                    out["l1_divergent_ceiling"] = round(256.0 / 181.0, 3)     # tools/ubench/gather.hip: 64 lanes x 4 loads on 64 distinct L2-resident lines in 181 cycles
+                for k in ("ta_busy", "td_busy", "tcp_pending_stall"):
+                    if k in dv:
+                        out[k + "_profiled_launch"] = round(dv[k], 3)
+                return out
         except Exception:
             continue
     return None
@@ -443,7 +455,7 @@ def main():
                                     "divergent_l2_reference": round(GATHER_DIVERGENT_L2, 4),
                                     "ratio_to_divergent_l2": round(gather_rate / GATHER_DIVERGENT_L2, 4),
                                     "clock_ghz": clock_ghz, "cus": num_cus},
-                         "valu": pmc_valu("crt_trace_kernel", sc.name, width, height) if (n == 1 and not args.shadows) else None},
+                         "valu": pmc_valu("crt_trace_kernel", sc.name, width, height, dev_s, clock_ghz, num_cus) if (n == 1 and not args.shadows) else None},
         }
         if sync_elapsed is not None:
             out["synchronous_frames"] = {"value": round(rays_per_frame * args.steps / sync_elapsed / 1e6, 2), "unit": "Mrays/s",

@@ -66,9 +66,21 @@ def main():
         d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
         d["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / max(1.0, c["SQ_ACTIVE_INST_VALU"] * 64.0)
-    if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
-        # SQ_BUSY_CYCLES is summed over the 32 shader engines (cycles); SQ_ACTIVE_INST_VALU over the 1024 SIMDs (quad-cycles)
-        d["valu_issue_busy"] = c["SQ_ACTIVE_INST_VALU"] / max(1.0, 1024.0 * (c["SQ_BUSY_CYCLES"] / 32.0) / 4.0)
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        # a wave64 VALU instruction holds its SIMD-32 for 2 cycles (MI355X_MICROARCH.md: constants table); GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs. (r02 first divided the wave-centric SQ_ACTIVE_INST_VALU by the SIMD cycles and read 0.83: that
+        # counter advances 4 cycles per instruction per WAVE, twice what the instruction costs the SIMD.)
+        kcyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        d["kernel_cycles_profiled_launch"] = kcyc
+        d["valu_issue_busy"] = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * kcyc)
+        d["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+            d["l1_line_accesses_per_launch"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            d["l1_line_accesses_per_cycle_per_cu"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * kcyc)
+        for k, name in (("TA_TA_BUSY_sum", "ta_busy"), ("TD_TD_BUSY_sum", "td_busy"), ("TCP_GATE_EN1_sum", "tcp_clocked"),
+                        ("TCP_PENDING_STALL_CYCLES_sum", "tcp_pending_stall"), ("TA_ADDR_STALLED_BY_TC_CYCLES_sum", "ta_addr_stalled_by_tc")):
+            if k in c:
+                d[name] = c[k] / (256.0 * kcyc)
     if "SQ_WAVE_CYCLES" in c and "SQ_WAVES" in c:
         d["wave_quad_cycles_per_wave"] = c["SQ_WAVE_CYCLES"] / max(1.0, c["SQ_WAVES"])
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
@@ -77,8 +89,6 @@ def main():
         d["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
     if "TCP_TCC_READ_REQ_sum" in c and "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
         d["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / max(1.0, c["TCP_TOTAL_CACHE_ACCESSES_sum"])
-    if "TCP_GATE_EN1_sum" in c and "GRBM_GUI_ACTIVE" in c:
-        d["tcp_busy_fraction_of_kernel"] = (c["TCP_GATE_EN1_sum"] / 256.0) / max(1.0, c["GRBM_GUI_ACTIVE"] / 8.0)
     out["derived"] = d
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)

@@ -16,4 +16,5 @@ rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-for
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $out/prof_${tag}_sq1 -- $S > $out/prof_${tag}_sq1.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR --output-format csv -d $out/prof_${tag}_sq2 -- $S > $out/prof_${tag}_sq2.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $out/prof_${tag}_misc -- $S > $out/prof_${tag}_misc.log 2>&1 || true
+tools/ta_only.sh $tag
 echo done

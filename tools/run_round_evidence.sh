@@ -4,14 +4,7 @@
 tag=${1:-r02}
 out=gpurun_out
 tools/run_profiles.sh $tag 2>&1 | tail -2
-: > $out/${tag}_bench_lines.jsonl
-python bench.py >> $out/${tag}_bench_lines.jsonl 2>$out/${tag}_bench.err
-for sc in multi-1M-dense sponza-sibenik nanosuit-demo sponza-class-250k cornell-1k; do
-  python bench.py --scene $sc --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
-done
-python bench.py --shadows --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
-python bench.py --width 3840 --height 2160 --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
-python bench.py --frames-in-flight 1 --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
+tools/run_bench_lines.sh $tag
 python tools/wave_timeline.py multi-1M 1920 1080 > $out/${tag}_wave_timeline.txt 2>&1
 CRT_TL_RANKS=8 python tools/wave_timeline.py multi-1M 3840 2160 >> $out/${tag}_wave_timeline.txt 2>&1
 python tools/cpu_baseline.py > $out/${tag}_cpu_baseline.md 2>&1
