@@ -50,6 +50,8 @@ for seed in range(first, first + count):
                 if s.counters() != fst or nd > 2:
                     print(f"seed {seed} camera {cam}: {nd} pixels differ / counters equal: {s.counters() == fst} (sizes {sizes}, grid {grid}, kinds {kinds})"); sys.exit(1)
                 tot["frames"] += 1; tot["skybox_flips"] += nd; tot["cap"] += fst["capHits"]
+    if (seed - first + 1) % 500 == 0:
+        print(f"  ... {seed - first + 1} scenes, all equal so far, {time.time() - t0:.0f} s", flush=True)
 print(f"fuzz seeds {first}..{first + count - 1}: {count} scenes, {tot['rays']} query rays ({tot['hits']} hits, {tot['nan_t']} with NaN t), "
       f"{tot['frames']} frames (odd seeds with shadow rays), {tot['cap']} rays stopped by the 250-pop cap: all hit records, counters and frames equal the "
       f"oracle's; {tot['skybox_flips']} skybox-texel flips tolerated; {time.time() - t0:.0f} s")
