@@ -9,6 +9,8 @@ for grp in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum" "TA_FLAT_READ_WAVEFRONTS_sum TA_BUSY
            "TD_TD_BUSY_sum TD_TCP_STALL_CYCLES_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "TCP_GATE_EN1_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"; do
   i=$((i+1))
   echo "pass $i: $grp"
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/prof_${tag}_vm$i -- $S > $out/prof_${tag}_vm$i.log 2>&1 || echo "pass $i failed (see $out/prof_${tag}_vm$i.log)"
+  # a pass that fails or hangs (these blocks have hung rocprofv3 before when asked for too many counters at once) ends the
+  # script: no further GPU step after a timeout
+  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/prof_${tag}_vm$i -- $S > $out/prof_${tag}_vm$i.log 2>&1 || { echo "pass $i failed (see $out/prof_${tag}_vm$i.log); stopping"; exit 1; }
 done
 echo done
