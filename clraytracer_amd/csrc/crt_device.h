@@ -53,10 +53,17 @@ typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
 #ifndef CRT_LDS_SLOTS
 #define CRT_LDS_SLOTS 20
 #endif
-#define CRT_OVF_SLOTS (CRT_STACK_DEPTH - CRT_LDS_SLOTS)
-#define CRT_OVF_WORDS_PER_BLOCK ((size_t)CRT_OVF_SLOTS * CRT_BLOCK)
-struct CrtStack {
-    static_assert(CRT_LDS_SLOTS >= 1 && CRT_LDS_SLOTS <= CRT_STACK_DEPTH, "LDS slots");
+// PARK: the last PARK of the wave's LDS slots do not hold stack entries but per-lane values "parked" across the traversals
+// (values that are live through them but not used in them, which would otherwise be spilled to scratch by the instantiations
+// that carry more state: the instance tree's candidate list, the shadow ray's n.l). The stack then has CRT_LDS_SLOTS - PARK
+// slots in LDS and the rest in the overflow block; the block is sized for the largest PARK.
+#define CRT_MAX_PARK 5
+#define CRT_OVF_SLOTS_MAX (CRT_STACK_DEPTH - (CRT_LDS_SLOTS - CRT_MAX_PARK))
+#define CRT_OVF_WORDS_PER_BLOCK ((size_t)CRT_OVF_SLOTS_MAX * CRT_BLOCK)
+template <int PARK>
+struct CrtStackT {
+    static constexpr int kLds = CRT_LDS_SLOTS - PARK;
+    static_assert(PARK >= 0 && PARK <= CRT_MAX_PARK && kLds >= 1 && kLds <= CRT_STACK_DEPTH, "LDS slots");
     crt_lds_u32_ptr lds;     // this lane's slot 0
     uint32_t* ovf;           // base of the launch's overflow area (wave-uniform)
     __device__ __forceinline__ uint32_t* overflow_slot(int k) const
@@ -64,21 +71,25 @@ struct CrtStack {
         uint32_t lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));      // keep the address arithmetic inside this (rarely taken) branch: hoisted out of the
                                             // traversal loop it costs two VGPRs for the whole kernel
-        return ovf + ((size_t)blockIdx.x * CRT_OVF_SLOTS + (size_t)k) * CRT_BLOCK + lane;
+        return ovf + ((size_t)blockIdx.x * CRT_OVF_SLOTS_MAX + (size_t)k) * CRT_BLOCK + lane;
     }
     __device__ __forceinline__ void write(int slot, uint32_t v) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
-        if (CRT_LDS_SLOTS >= CRT_STACK_DEPTH || s < CRT_LDS_SLOTS) lds[s * 64] = v;
-        else *overflow_slot(s - CRT_LDS_SLOTS) = v;
+        if (kLds >= CRT_STACK_DEPTH || s < kLds) lds[s * 64] = v;
+        else *overflow_slot(s - kLds) = v;
     }
     __device__ __forceinline__ uint32_t read(int slot) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
-        if (CRT_LDS_SLOTS >= CRT_STACK_DEPTH || s < CRT_LDS_SLOTS) return lds[s * 64];
-        return *overflow_slot(s - CRT_LDS_SLOTS);
+        if (kLds >= CRT_STACK_DEPTH || s < kLds) return lds[s * 64];
+        return *overflow_slot(s - kLds);
     }
+    // parked value k (0 <= k < PARK) of this lane
+    __device__ __forceinline__ void park(int k, uint32_t v) const { lds[(kLds + k) * 64] = v; }
+    __device__ __forceinline__ uint32_t parked(int k) const { return lds[(kLds + k) * 64]; }
 };
+typedef CrtStackT<0> CrtStack;
 #ifndef CRT_SPLIT_BETA
 #define CRT_SPLIT_BETA 1.2f
 #endif
@@ -135,9 +146,6 @@ struct CrtFrame {
     const uint32_t* listLen;  // entries in each XCD's list (tiles + 3 extra entries per split tile)
     int listCap;              // capacity of one XCD's list = slotsPerXcd + 3 * CRT_MAX_SPLIT
     uint32_t* cost;           // per tile: shader cycles the wave spent on it this frame (feeds the next frame's order)
-    uint32_t smallPacket;     // packets with at most this many working lanes run every step kind per trip (closest_hit)
-    uint32_t suspendAt;       // straggler hand-off (crt_trace_fast_kernel): suspend the remaining lanes once this few still work; 0 = never
-    uint32_t suspendAfter;    // ... and only in waves that have run at least this many trips in the current bounce
     uint32_t epilogue;        // crt_trace_kernel: per-pixel stages applied before the pixel is stored (CRT_EPILOGUE_*); 0 = the plain HDR value
     uint32_t* packOut;        // with CRT_EPILOGUE_QUANTIZE: also store the pixel's RGBA8 bytes here (the frame a read-back delivers); or null
 };
@@ -304,7 +312,8 @@ struct Traversal {
         active = false;
     }
     // `while (currentNodeIndex > 0 && protection++ < 250) node = stack[--currentNodeIndex]` (kernel_main.cl:131-133)
-    __device__ __forceinline__ void pop_next(const CrtStack& stack, Closest& c, LaneCounters& lc)
+    template <class STK>
+    __device__ __forceinline__ void pop_next(const STK& stack, Closest& c, LaneCounters& lc)
     {
         if (sp > 0) {
             if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; finish(c); }
@@ -326,7 +335,8 @@ struct Traversal {
         if (COUNT) { lc.traversals++; lc.pops++; }
     }
     // kernel_main.cl:142-157: fetch the child pair, two slab tests, near child first, far child pushed
-    __device__ __forceinline__ void inner(const CrtDevScene& S, const CrtStack& stack, Closest& c, LaneCounters& lc)
+    template <class STK>
+    __device__ __forceinline__ void inner(const CrtDevScene& S, const STK& stack, Closest& c, LaneCounters& lc)
     {
         const float4* p = S.pairs + (size_t)ref * 4;            // one aligned 64-byte record
         const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
@@ -351,8 +361,8 @@ struct Traversal {
     }
     // kernel_main.cl:135-140: every triangle of the leaf, then the next pop.
     // ANYHIT (shadow rays): the traversal ends at the first triangle that passes.
-    template <bool ANYHIT = false>
-    __device__ __forceinline__ void leaf(const CrtDevScene& S, const CrtStack& stack, Closest& c, LaneCounters& lc)
+    template <bool ANYHIT, class STK>
+    __device__ __forceinline__ void leaf(const CrtDevScene& S, const STK& stack, Closest& c, LaneCounters& lc)
     {
         const uint32_t first = ref & 0x00FFFFFFu;
         uint32_t n = (ref >> 24) & 0x7Fu;
@@ -397,38 +407,45 @@ __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& 
 }
 
 // Candidate instances of one ray from the instance tree: up to CRT_TLAS_LIST indices (16 bits each, unordered, 0xFFFF =
-// empty) in four registers; returns false when the lane would need more. The traversal stack is idle at this point
+// empty) in four words; returns false when the lane would need more. The traversal stack is idle at this point
 // and serves as the tree stack. Scenes with hundreds of instances (upstream allows 401 and loops over all of them for
 // every ray, kernel_main.cl:198) spend their time here otherwise: 401 instances, 1920x1080: 1.12 ms -> see DESIGN.md.
-struct CandidateList { uint32_t w[CRT_TLAS_LIST / 2]; uint32_t n; };
-__device__ __forceinline__ bool candidate_list_add(CandidateList& L, uint32_t idx)
+// The four words live in the stack's parked LDS slots 0..3 (CrtStackT<PARK >= 4>), not in registers: they are read once per
+// instance entry, and as registers they were what the TLAS instantiations spilled to scratch (rounds 1-2: 48 B per lane).
+#define CRT_TLAS_PARK (CRT_TLAS_LIST / 2)
+template <class STK>
+__device__ __forceinline__ bool candidate_list_add(const STK& stack, uint32_t& n, uint32_t idx)
 {
-    if (L.n >= (uint32_t)CRT_TLAS_LIST) return false;
-    const uint32_t sh = (L.n & 1u) * 16u, m = ~(0xFFFFu << sh), v = idx << sh;
-#pragma unroll
-    for (int k = 0; k < CRT_TLAS_LIST / 2; ++k) if ((L.n >> 1) == (uint32_t)k) L.w[k] = (L.w[k] & m) | v;
-    L.n++;
+    if (n >= (uint32_t)CRT_TLAS_LIST) return false;
+    const uint32_t sh = (n & 1u) * 16u, m = ~(0xFFFFu << sh), v = idx << sh;
+    const int k = (int)(n >> 1);
+    stack.park(k, (stack.parked(k) & m) | v);
+    n++;
     return true;
 }
 // smallest candidate index greater than `after` (after = -1 for the first), or 0xFFFF
-__device__ __forceinline__ uint32_t candidate_list_next(const CandidateList& L, int after)
+template <class STK>
+__device__ __forceinline__ uint32_t candidate_list_next(const STK& stack, int after)
 {
     uint32_t best = 0xFFFFu;
 #pragma unroll
-    for (int k = 0; k < CRT_TLAS_LIST / 2; ++k) {
-        const uint32_t lo = L.w[k] & 0xFFFFu, hi = L.w[k] >> 16;
+    for (int k = 0; k < CRT_TLAS_PARK; ++k) {
+        const uint32_t w = stack.parked(k);
+        const uint32_t lo = w & 0xFFFFu, hi = w >> 16;
         if ((int)lo > after && lo < best) best = lo;
         if ((int)hi > after && hi < best) best = hi;
     }
     return best;
 }
-__device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d, const CrtStack& stack, CandidateList& L)
+// fills the parked list; `n` receives the number of candidates
+template <class STK>
+__device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d, const STK& stack, uint32_t& n)
 {
 #pragma unroll
-    for (int k = 0; k < CRT_TLAS_LIST / 2; ++k) L.w[k] = 0xFFFFFFFFu;
-    L.n = 0;
+    for (int k = 0; k < CRT_TLAS_PARK; ++k) stack.park(k, 0xFFFFFFFFu);
+    n = 0;
     bool ok = true;
-    for (uint32_t k = 0; k < S.numAlways; ++k) { const uint32_t i = S.alwaysList[k]; if (i < S.numInstances) ok = candidate_list_add(L, i) && ok; }
+    for (uint32_t k = 0; k < S.numAlways; ++k) { const uint32_t i = S.alwaysList[k]; if (i < S.numInstances) ok = candidate_list_add(stack, n, i) && ok; }
     if (S.tlasNodes == 0) return ok;
     const float dd = dot3(d, d);
     uint32_t node = 0; int sp = 0;
@@ -439,7 +456,7 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
             // children: a leaf child is tested through its own sphere when it is popped as a one-node subtree
             if (nd.left & CRT_TLAS_LEAF) {
                 const uint32_t i = nd.left & 0xFFFFu;             // a leaf NODE: left = leaf | instance, right unused
-                if (i < S.numInstances) ok = candidate_list_add(L, i) && ok;
+                if (i < S.numInstances) ok = candidate_list_add(stack, n, i) && ok;
             } else { stack.write(sp, nd.right); sp++; node = nd.left; descend = true; }
         }
         if (!descend) { if (sp == 0) break; --sp; node = stack.read(sp); }
@@ -447,38 +464,32 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
     return ok;
 }
 
-// Packets with at most this many lanes still working advance every lane through every step kind each trip
-// (latency of the longest ray matters, issue slots do not); larger packets vote for one step kind per trip.
-#ifndef CRT_SUSPEND_AT
-#define CRT_SUSPEND_AT 0             // straggler hand-off (opt-in, CRT_SUSPEND_AT=8): the last lanes of a wave leave for crt_straggler_kernel when this few still work
-#endif
-// ALLSTEPS trips (frames in flight) run enter, CRT_INNER_BEFORE inner steps, leaf, CRT_INNER_AFTER inner steps
-#ifndef CRT_INNER_BEFORE
-#define CRT_INNER_BEFORE 1
-#endif
-#ifndef CRT_INNER_AFTER
-#define CRT_INNER_AFTER 1
-#endif
-#ifndef CRT_SMALL_PACKET
-#define CRT_SMALL_PACKET 64          // synchronous frames too since the two-inner-steps trip (6.3 vs 5.9 Gray/s with the vote at 16); queries keep 16
-#endif
-#ifndef CRT_SMALL_PACKET_ASYNC
-#define CRT_SMALL_PACKET_ASYNC 64    // frames in flight: every packet runs every step kind per trip (voting lost 3 % at 7 waves/SIMD)
-#endif
-
-// Closest hit of one ray per lane over all instances (kernel_main.cl:198-217), driven in flat trips:
-//  * large packets: exactly ONE step kind runs per trip, the one most lanes are waiting for (three ballots +
-//    popcounts), so each section's code is issued for many lanes and no lane waits for a neighbour's whole descent.
-//    Measured on multi-1M: the nested descend-then-leaf loops needed 2.66 M wave-trips at 16 active lanes and 1979
-//    trips for a tile whose longest ray has 361 visits; voted trips need 1.64 M at 26 lanes and 738.
-//  * small packets (quadrant waves of split tiles, tails): all three kinds run, a lane may enter, visit and test
-//    a leaf in the same trip.
+// Closest hit of one ray per lane over all instances (kernel_main.cl:198-217), driven in flat trips: every lane owns a
+// Traversal and a trip of the wave's loop is  enter -> inner -> leaf -> inner  for whichever lanes are at that step (a lane
+// may enter an instance, visit a node and test a leaf in the same trip; a lane that popped an inner node out of a leaf or a
+// miss goes on at once). One ballot per trip decides when the wave is done. (Rounds 1-2 voted for ONE step kind per trip in
+// packets with many working lanes -- three ballots, popcounts and the majority logic; at 8 waves/SIMD that lost 6 % and
+// the second inner step gained another 10 %; the voted form was retired in round 3.)
 // ANYHIT (shadow rays, CRT_RENDER_SHADOWS): a lane stops at the first triangle that passes -- inside the leaf, and
 // for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
 // first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
-// ALLSTEPS (frames in flight): no vote at all, see the loop.
-template <bool COUNT, bool ITERS = false, bool ANYHIT = false, bool TLAS = false, bool ALLSTEPS = false>
-__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, const CrtStack& stack, LaneCounters& lc, uint32_t smallPacket)
+// ITERS (stamped diagnostic launches): the counters record wave-level trips instead of per-ray work.
+template <bool COUNT, bool ITERS, bool ANYHIT, class STK>
+__device__ __forceinline__ void trip_steps(const CrtDevScene& S, const STK& stack, Traversal<COUNT>& T, Closest& c, LaneCounters& lc, bool done)
+{
+    if (!done && T.at_inner()) {
+        if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
+        T.inner(S, stack, c, lc);
+    }
+    if (!done && T.at_leaf()) {
+        if (ITERS) { if (first_active_lane()) lc.triTests++; }
+        T.template leaf<ANYHIT>(S, stack, c, lc);
+    }
+    if (!done && T.at_inner()) T.inner(S, stack, c, lc);      // lanes that just popped an inner node go on at once
+}
+
+template <bool COUNT, bool ITERS = false, bool ANYHIT = false, bool TLAS = false, class STK = CrtStack>
+__device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d, const STK& stack, LaneCounters& lc)
 {
     Closest c;
     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
@@ -489,35 +500,30 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
         // Many instances: every lane collects its (few) candidates from the instance tree and walks them in ascending
         // order -- the same instances, in the same order, as the chunked loop below would. A wave in which some lane
         // has more than CRT_TLAS_LIST candidates takes the chunked loop instead.
-        CandidateList L;
-        const bool fits = tlas_candidates(S, o, d, stack, L);
+        static_assert(!TLAS || STK::kLds <= CRT_LDS_SLOTS - CRT_TLAS_PARK, "the candidate list needs CRT_TLAS_PARK parked slots");
+        uint32_t listed = 0;
+        const bool fits = tlas_candidates(S, o, d, stack, listed);
         if (__ballot(!fits) == 0) {
             int prev = -1;                                        // last instance entered (ANYHIT + COUNT: culled ones in between)
-            if (COUNT && !ANYHIT) { const uint32_t culled = S.numInstances - L.n; lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; lc.culled += culled; }
+            if (COUNT && !ANYHIT) { const uint32_t culled = S.numInstances - listed; lc.traversals += culled; lc.pops += culled; lc.innerVisits += culled; lc.culled += culled; }
             bool done = false;
             for (;;) {
                 const bool wEnter = !done && !T.active;
                 const bool wInner = !done && T.at_inner();
                 const bool wLeaf = !done && T.at_leaf();
-                const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
-                if (nE + nI + nL == 0) break;
-                const bool all = (nE + nI + nL) <= smallPacket;
-                const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
-                if (all || (!runI && !runL)) {
-                    if (wEnter) {
-                        const uint32_t k = (ANYHIT && c.anyHit) ? 0xFFFFu : candidate_list_next(L, prev);
-                        if (k == 0xFFFFu) {
-                            done = true;
-                            if (COUNT && ANYHIT && !c.anyHit) { const uint32_t n = S.numInstances - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; }
-                        } else {
-                            if (COUNT && ANYHIT) { const uint32_t n = k - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; }
-                            prev = (int)k;
-                            T.enter(S, k, o, d, c.distance, lc);
-                        }
+                if (__ballot(wEnter || wInner || wLeaf) == 0) break;      // (this exact form: `__ballot(!done)` makes the register allocator spill 30 VGPRs)
+                if (wEnter) {
+                    const uint32_t k = (ANYHIT && c.anyHit) ? 0xFFFFu : candidate_list_next(stack, prev);
+                    if (k == 0xFFFFu) {
+                        done = true;
+                        if (COUNT && ANYHIT && !c.anyHit) { const uint32_t n = S.numInstances - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; }
+                    } else {
+                        if (COUNT && ANYHIT) { const uint32_t n = k - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; }
+                        prev = (int)k;
+                        T.enter(S, k, o, d, c.distance, lc);
                     }
                 }
-                if (all || runI) { if (!done && T.at_inner()) T.inner(S, stack, c, lc); }
-                if (all || runL) { if (!done && T.at_leaf()) T.template leaf<ANYHIT>(S, stack, c, lc); }
+                trip_steps<COUNT, false, ANYHIT>(S, stack, T, c, lc, done);
             }
             return c;
         }
@@ -534,56 +540,26 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
             const bool wEnter = !done && !T.active;
             const bool wInner = !done && T.at_inner();
             const bool wLeaf = !done && T.at_leaf();
-            bool all, runI = false, runL = false;
-            if (ALLSTEPS) {                                        // every packet runs every step kind: one ballot decides when the wave is done
-                if (__ballot(wEnter || wInner || wLeaf) == 0) break;
-                all = true;
-            } else {
-                const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
-                if (nE + nI + nL == 0) break;
-                all = (nE + nI + nL) <= smallPacket;
-                runI = nI > 0 && nI >= nE && nI >= nL; runL = !runI && nL > 0 && nL >= nE;
-            }
+            if (__ballot(wEnter || wInner || wLeaf) == 0) break;
             if (ITERS) { if (first_active_lane()) lc.pops++; }
-            if (all || (!runI && !runL)) {
-                if (wEnter) {
-                    if (ANYHIT && c.anyHit) done = true;           // occluded: later instances are never visited
-                    else if (cand == 0) {                          // this lane is finished with the chunk
-                        done = true;
-                        if (COUNT && ANYHIT) { const uint32_t n = (uint32_t)__popcll(culledLeft); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; culledLeft = 0; }
-                    } else {
-                        if (ITERS) { if (first_active_lane()) lc.traversals++; }
-                        const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
-                        cand &= cand - 1;
-                        if (COUNT && ANYHIT) {
-                            const unsigned long long below = culledLeft & ((1ull << k) - 1ull);
-                            const uint32_t n = (uint32_t)__popcll(below);
-                            lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; culledLeft &= ~below;
-                        }
-                        T.enter(S, base + k, o, d, c.distance, lc);
+            if (wEnter) {
+                if (ANYHIT && c.anyHit) done = true;           // occluded: later instances are never visited
+                else if (cand == 0) {                          // this lane is finished with the chunk
+                    done = true;
+                    if (COUNT && ANYHIT) { const uint32_t n = (uint32_t)__popcll(culledLeft); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; culledLeft = 0; }
+                } else {
+                    if (ITERS) { if (first_active_lane()) lc.traversals++; }
+                    const uint32_t k = (uint32_t)__ffsll((long long)cand) - 1u;
+                    cand &= cand - 1;
+                    if (COUNT && ANYHIT) {
+                        const unsigned long long below = culledLeft & ((1ull << k) - 1ull);
+                        const uint32_t n = (uint32_t)__popcll(below);
+                        lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; culledLeft &= ~below;
                     }
+                    T.enter(S, base + k, o, d, c.distance, lc);
                 }
             }
-            if (all || runI) {
-                if (!done && T.at_inner()) {
-                    if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
-                    T.inner(S, stack, c, lc);
-                }
-            }
-            if (ALLSTEPS) {
-#pragma unroll
-                for (int r = 1; r < CRT_INNER_BEFORE; ++r) { if (!done && T.at_inner()) T.inner(S, stack, c, lc); }
-            }
-            if (all || runL) {
-                if (!done && T.at_leaf()) {
-                    if (ITERS) { if (first_active_lane()) lc.triTests++; }
-                    T.template leaf<ANYHIT>(S, stack, c, lc);
-                }
-            }
-            if (ALLSTEPS) {
-#pragma unroll
-                for (int r = 0; r < CRT_INNER_AFTER; ++r) { if (!done && T.at_inner()) T.inner(S, stack, c, lc); }   // lanes that just popped an inner node go on at once
-            }
+            trip_steps<COUNT, ITERS, ANYHIT>(S, stack, T, c, lc, done);
         }
     }
     return c;
@@ -738,117 +714,4 @@ __device__ __forceinline__ int shade_bounce(const CrtDevScene& S, const Closest&
     if (DEFER_ENERGY) *ndlOut = ndl;
     else ps.energy = ps.energy * specular_x(ndl, 1.0f);      // shadow = 1.0f (kernel_main.cl:258: no shadow ray upstream)
     return 1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Straggler hand-off (round 2): resumable closest-hit walk + the record a suspended ray travels in.
-//
-// The rays of one 8x8 tile need very different numbers of steps (wave duration p50 18 us, p90 288 us on multi-1M), and a
-// wave-trip costs the same VALU issue slots whether 60 lanes or 2 take part: on multi-1M a third of all wave-trips run
-// with <= 8 working lanes and hold 3 % of the lane-steps (oracle per-pixel costs). So when the
-// working lanes of a wave drop to `suspendAt`, those lanes write their complete state -- path, running best hit,
-// traversal position, remaining candidate instances, traversal stack -- to a queue and leave; the rest of the wave goes on
-// to shading and the next bounce at once. A second kernel (crt_straggler_kernel) picks the suspended rays up 64 at a
-// time and finishes them: dense packets of long rays instead of mostly empty waves. Every ray still performs exactly
-// upstream's sequence of instance entries, node visits and triangle tests; only WHICH wave performs the tail changes.
-// Used by the plain launch (no counters, stamps, shadow rays; <= 64 instances); everything else keeps closest_hit.
-// ------------------------------------------------------------------------------------------------
-struct CrtSuspended {                 // 256 B per suspended ray
-    uint32_t pixel;                   // py * width + px
-    uint32_t state;                   // bounce | anyHit << 1 | active << 2 | inters << 3 | sp << 8 (9 bits) | prot << 20 (9 bits)
-    uint32_t curInst, ref;
-    float o[3], d[3], result[3], energy;
-    float cDistance; int32_t cInstance; float cT, cU, cV; uint32_t cTri;
-    float mo[3], md[3];
-    float tT, tU, tV; uint32_t tTri;
-    uint32_t candLo, candHi;
-    uint32_t stack[CRT_STACK_DEPTH];
-};
-static_assert(sizeof(CrtSuspended) == 256, "CrtSuspended is 64 dwords");
-
-struct RayWalk { Traversal<false> T; Closest c; unsigned long long cand; };
-
-__device__ __forceinline__ void walk_begin(const CrtDevScene& S, v3 o, v3 d, RayWalk& W)
-{
-    LaneCounters lc;
-    W.c.distance = 99999.0f; W.c.hitInstance = 0; W.c.anyHit = 0;
-    W.c.hit.t = 0.0f; W.c.hit.u = 0.0f; W.c.hit.v = 0.0f; W.c.hit.tri = 0;
-    W.T.reset();
-    W.cand = candidate_mask<false>(S, o, d, 0u, S.numInstances, lc);       // <= 64 instances: one chunk
-}
-__device__ __forceinline__ void walk_idle(RayWalk& W) { W.T.reset(); W.cand = 0; W.c.distance = 99999.0f; W.c.hitInstance = 0; W.c.anyHit = 0; W.c.hit.t = 0.f; W.c.hit.u = 0.f; W.c.hit.v = 0.f; W.c.hit.tri = 0; }
-
-// Advances every lane's walk; returns when no lane has work left (false) or -- SUSPEND -- when at most `suspendAt` lanes
-// still have (true for exactly those lanes: the caller suspends them). The loop body is closest_hit's.
-template <bool SUSPEND>
-__device__ __forceinline__ bool walk_run(const CrtDevScene& S, v3 o, v3 d, const CrtStack& stack, RayWalk& W, uint32_t smallPacket, uint32_t suspendAt,
-                                         uint32_t suspendAfter = 0)
-{
-    LaneCounters lc;
-    Traversal<false>& T = W.T;
-    uint32_t trips = 0;
-    for (;; ++trips) {
-        const bool wEnter = !T.active && W.cand != 0;
-        const bool wInner = T.at_inner();
-        const bool wLeaf = T.at_leaf();
-        const uint32_t nE = (uint32_t)__popcll(__ballot(wEnter)), nI = (uint32_t)__popcll(__ballot(wInner)), nL = (uint32_t)__popcll(__ballot(wLeaf));
-        const uint32_t n = nE + nI + nL;
-        if (n == 0) return false;
-        // only waves that have already run `suspendAfter` trips hand their last lanes off: rays that are still going then
-        // are the long ones (the distribution is heavy-tailed); the short tails of ordinary tiles are not worth 256 B of state
-        if (SUSPEND) { if (n <= suspendAt && trips >= suspendAfter) return wEnter || wInner || wLeaf; }
-        const bool all = n <= smallPacket;
-        const bool runI = nI > 0 && nI >= nE && nI >= nL, runL = !runI && nL > 0 && nL >= nE;
-        if (all || (!runI && !runL)) {
-            if (wEnter) {
-                const uint32_t k = (uint32_t)__ffsll((long long)W.cand) - 1u;
-                W.cand &= W.cand - 1;
-                T.enter(S, k, o, d, W.c.distance, lc);
-            }
-        }
-        if (all || runI) { if (T.at_inner()) T.inner(S, stack, W.c, lc); }
-        if (all || runL) { if (T.at_leaf()) T.template leaf<false>(S, stack, W.c, lc); }
-    }
-}
-
-__device__ __forceinline__ void suspend_store(CrtSuspended* __restrict__ r, uint32_t pixel, int bounce, const PathState& ps, const RayWalk& W, const CrtStack& stack)
-{
-    const Traversal<false>& T = W.T;
-    uint4* q = reinterpret_cast<uint4*>(r);
-    const uint32_t sp = (uint32_t)T.sp > 511u ? 511u : (uint32_t)T.sp;
-    const uint32_t state = (uint32_t)bounce | ((uint32_t)(W.c.anyHit != 0) << 1) | ((uint32_t)T.active << 2) | ((uint32_t)(T.inters != 0) << 3) | (sp << 8) | ((uint32_t)T.prot << 20);
-    q[0] = make_uint4(pixel, state, T.curInst, T.ref);
-    q[1] = make_uint4(__float_as_uint(ps.o.x), __float_as_uint(ps.o.y), __float_as_uint(ps.o.z), __float_as_uint(ps.d.x));
-    q[2] = make_uint4(__float_as_uint(ps.d.y), __float_as_uint(ps.d.z), __float_as_uint(ps.result.x), __float_as_uint(ps.result.y));
-    q[3] = make_uint4(__float_as_uint(ps.result.z), __float_as_uint(ps.energy), __float_as_uint(W.c.distance), (uint32_t)W.c.hitInstance);
-    q[4] = make_uint4(__float_as_uint(W.c.hit.t), __float_as_uint(W.c.hit.u), __float_as_uint(W.c.hit.v), W.c.hit.tri);
-    q[5] = make_uint4(__float_as_uint(T.mo.x), __float_as_uint(T.mo.y), __float_as_uint(T.mo.z), __float_as_uint(T.md.x));
-    q[6] = make_uint4(__float_as_uint(T.md.y), __float_as_uint(T.md.z), __float_as_uint(T.tr.t), __float_as_uint(T.tr.u));
-    q[7] = make_uint4(__float_as_uint(T.tr.v), T.tr.tri, (uint32_t)W.cand, (uint32_t)(W.cand >> 32));
-    const uint32_t live = T.sp > CRT_STACK_DEPTH ? (uint32_t)CRT_STACK_DEPTH : (uint32_t)(T.sp < 0 ? 0 : T.sp);   // slots that hold pending entries
-    for (uint32_t s = 0; s < live; ++s) r->stack[s] = stack.read((int)s);
-}
-
-__device__ __forceinline__ void suspend_load(const CrtSuspended* __restrict__ r, uint32_t& pixel, int& bounce, PathState& ps, RayWalk& W, const CrtStack& stack)
-{
-    const uint4* q = reinterpret_cast<const uint4*>(r);
-    const uint4 a = q[0], b = q[1], c2 = q[2], d2 = q[3], e = q[4], f = q[5], g2 = q[6], h = q[7];
-    Traversal<false>& T = W.T;
-    pixel = a.x; bounce = (int)(a.y & 1u);
-    W.c.anyHit = (int)((a.y >> 1) & 1u); T.active = ((a.y >> 2) & 1u) != 0; T.inters = (int)((a.y >> 3) & 1u);
-    T.sp = (int)((a.y >> 8) & 0x1FFu); T.prot = (int)((a.y >> 20) & 0x1FFu);
-    T.curInst = a.z; T.ref = a.w;
-    ps.o = mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
-    ps.d = mk3(__uint_as_float(b.w), __uint_as_float(c2.x), __uint_as_float(c2.y));
-    ps.result = mk3(__uint_as_float(c2.z), __uint_as_float(c2.w), __uint_as_float(d2.x));
-    ps.energy = __uint_as_float(d2.y);
-    W.c.distance = __uint_as_float(d2.z); W.c.hitInstance = (int)d2.w;
-    W.c.hit.t = __uint_as_float(e.x); W.c.hit.u = __uint_as_float(e.y); W.c.hit.v = __uint_as_float(e.z); W.c.hit.tri = e.w;
-    T.mo = mk3(__uint_as_float(f.x), __uint_as_float(f.y), __uint_as_float(f.z));
-    T.md = mk3(__uint_as_float(f.w), __uint_as_float(g2.x), __uint_as_float(g2.y));
-    T.inv = mk3(1.0f / T.md.x, 1.0f / T.md.y, 1.0f / T.md.z);        // as Traversal::enter computes it
-    T.tr.t = __uint_as_float(g2.z); T.tr.u = __uint_as_float(g2.w); T.tr.v = __uint_as_float(h.x); T.tr.tri = h.y;
-    W.cand = (unsigned long long)h.z | ((unsigned long long)h.w << 32);
-    const uint32_t live = T.sp > CRT_STACK_DEPTH ? (uint32_t)CRT_STACK_DEPTH : (uint32_t)T.sp;
-    for (uint32_t s = 0; s < live; ++s) stack.write((int)s, r->stack[s]);
 }

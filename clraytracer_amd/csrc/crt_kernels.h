@@ -232,14 +232,15 @@ __device__ __forceinline__ float quantize1(float x) { return (float)unorm8(x) / 
 // product is 0 whatever the shadow factor).
 // TLAS: candidates come from the instance tree instead of the linear sphere loop (scenes with many instances).
 // REFRACT (CRT_RENDER_REFRACTION, the other README TODO of upstream, oracle-defined): translucent materials transmit.
-// ALLSTEPS: every packet runs every step kind per trip (what frames in flight use: smallPacket = 64), compiled without the
-// vote -- one ballot per trip instead of three ballots, three popcounts and the majority logic (+3 %).
-template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false, bool REFRACT = false, bool ALLSTEPS = false>
+template <bool COUNT, bool STAMP = false, bool SHADOW = false, bool TLAS = false, bool REFRACT = false>
 __global__ __launch_bounds__(CRT_BLOCK, (COUNT || STAMP) ? CRT_WAVES_PER_SIMD_COUNT : CRT_WAVES_PER_SIMD)
 void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
-    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
+    // parked LDS slots (CrtStackT): the instance tree's candidate list [0, 4) and the shadow ray's n.l behind it
+    constexpr int kParkNdl = TLAS ? CRT_TLAS_PARK : 0;
+    typedef CrtStackT<kParkNdl + (SHADOW ? 1 : 0)> Stack;
+    const Stack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
     if (STAMP) { t0rt = __builtin_amdgcn_s_memrealtime(); t0c = __builtin_amdgcn_s_memtime(); }
@@ -255,19 +256,30 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
         ps.energy = 1.0f;
         for (int bounce = 0; bounce < 2; ++bounce) {
             if (COUNT) { lc.rays++; if (bounce == 0) lc.primary++; else lc.secondary++; }
-            Closest c = closest_hit<COUNT, STAMP, false, TLAS, ALLSTEPS>(S, ps.o, ps.d, stack, lc, F.smallPacket);
+            // SHADOW: the path's energy waits in the parked LDS slot while the ray is traced (the one value these instantiations
+            // would otherwise spill to scratch); the shadow ray's n.l uses the same slot later, when the energy is dead
+            if (SHADOW) stack.park(kParkNdl, __float_as_uint(ps.energy));
+            Closest c = closest_hit<COUNT, STAMP, false, TLAS>(S, ps.o, ps.d, stack, lc);
+            if (SHADOW) ps.energy = __uint_as_float(stack.parked(kParkNdl));
             float ndl = 0.0f;
             const int cont = shade_bounce<SHADOW, REFRACT>(S, c, ps, bounce, F.lightY, F.lightZ, &ndl);
             if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
             if (!cont) break;
             if (SHADOW && cont == 1) {
-                float shadow = 1.0f;
-                if (bounce == 0 && ndl > 0.0f) {
-                    if (COUNT) { lc.rays++; lc.shadowRays++; }
-                    const Closest sc = closest_hit<COUNT, false, true, TLAS, ALLSTEPS>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc, F.smallPacket);
-                    if (sc.anyHit) { shadow = 0.0f; if (COUNT) lc.shadowHits++; }
-                }
-                ps.energy = ps.energy * specular_x(ndl, shadow);
+                if (bounce == 0) {
+                    // the energy is still its initial 1.0f here (only a transmitted ray, cont == 2, changes it before), so it
+                    // need not stay in a register across the any-hit traversal: 1.0f * x == x bit for bit
+                    // ... and n.l waits in a parked LDS slot meanwhile
+                    float shadow = 1.0f;
+                    if (ndl > 0.0f) {
+                        if (COUNT) { lc.rays++; lc.shadowRays++; }
+                        stack.park(kParkNdl, __float_as_uint(ndl));
+                        const Closest sc = closest_hit<COUNT, false, true, TLAS>(S, ps.o, neg3(mk3(0.0f, F.lightY, F.lightZ)), stack, lc);
+                        if (sc.anyHit) { shadow = 0.0f; if (COUNT) lc.shadowHits++; }
+                        ndl = __uint_as_float(stack.parked(kParkNdl));
+                    }
+                    ps.energy = specular_x(ndl, shadow);
+                } else ps.energy = ps.energy * specular_x(ndl, 1.0f);
             }
         }
         // the pixel coordinates are recomputed here rather than kept alive through both traversals (4 VGPRs that were
@@ -313,106 +325,6 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
     }
 }
 
-// ---- Trace with straggler hand-off (the plain launch: no counters / stamps / shadow rays, <= 64 instances) ----------
-// Same per-pixel work as crt_trace_kernel; when at most F.suspendAt lanes of the wave still have traversal work, those
-// lanes are suspended into `queue` (crt_device.h, CrtSuspended) and finished by crt_straggler_kernel in dense packets.
-struct CrtSuspendQueue { CrtSuspended* records; uint32_t* count; uint32_t* head; uint32_t capacity; };
-
-template <bool REFRACT>
-__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD)
-void crt_trace_fast_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, CrtSuspendQueue Q)
-{
-    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
-    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
-    int px, py, costSlot = -1;
-    bool isQuadrant = false;
-    const unsigned long long tc0 = F.cost ? __builtin_amdgcn_s_memtime() : 0ull;
-    const bool active = lane_pixel(F, px, py, &costSlot, &isQuadrant);
-    PathState ps;
-    ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
-    ps.d = active ? raygen_dir(F, px, py) : mk3(0.0f, 0.0f, 1.0f);
-    ps.result = mk3(0.0f, 0.0f, 0.0f);
-    ps.energy = 1.0f;
-    bool alive = active;                       // this lane still owns its pixel (not finished, not suspended)
-    bool suspended = false;
-    for (int bounce = 0; bounce < 2; ++bounce) {
-        RayWalk W;
-        if (alive) walk_begin(S, ps.o, ps.d, W); else walk_idle(W);
-        const bool unfinished = walk_run<true>(S, ps.o, ps.d, stack, W, F.smallPacket, F.suspendAt, F.suspendAfter);
-        const unsigned long long m = __ballot(unfinished);
-        if (m != 0) {                          // wave-uniform: the working lanes leave together
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(Q.count, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            if (unfinished) {
-                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-                int b2 = blockIdx.x, lane2 = (int)(threadIdx.x & 63);
-                asm volatile("" : "+s"(b2), "+v"(lane2));
-                int qx, qy;
-                (void)lane_pixel(F, qx, qy, nullptr, nullptr, b2, lane2);
-                suspend_store(Q.records + (size_t)(base + rank), (uint32_t)qy * (uint32_t)F.width + (uint32_t)qx, bounce, ps, W, stack);
-                alive = false; suspended = true;
-            }
-        }
-        if (alive) {
-            float ndl = 0.0f;
-            const int cont = shade_bounce<false, REFRACT>(S, W.c, ps, bounce, F.lightY, F.lightZ, &ndl);
-            if (!cont) alive = false;          // finished: the pixel is written below
-        }
-        if (__ballot(alive) == 0) break;
-    }
-    if (active && !suspended) {
-        int b2 = blockIdx.x, lane2 = (int)(threadIdx.x & 63);
-        asm volatile("" : "+s"(b2), "+v"(lane2));
-        int qx, qy;
-        (void)lane_pixel(F, qx, qy, nullptr, nullptr, b2, lane2);
-        out[(size_t)qy * (size_t)F.width + (size_t)qx] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
-    }
-    if (F.cost && costSlot >= 0) {
-        unsigned long long dt = __builtin_amdgcn_s_memtime() - tc0;
-        if (isQuadrant) dt >>= 1;
-        if ((threadIdx.x & 63) == 0) atomicAdd(&F.cost[costSlot], dt > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)dt);
-    }
-}
-
-// Finishes the suspended rays: resident waves pull packets of 64 records (one atomic per packet) until the queue is empty.
-// A ray suspended during its first bounce also gets its second one here (traced to completion: no second hand-off).
-template <bool REFRACT>
-__global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD_COUNT)      // few, long-lived waves: registers matter here, occupancy does not
-void crt_straggler_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, CrtSuspendQueue Q)
-{
-    __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
-    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
-    uint32_t total = *Q.count;
-    total = total < Q.capacity ? total : Q.capacity;
-    for (;;) {
-        uint32_t base = 0;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(Q.head, (uint32_t)CRT_BLOCK);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= total) break;
-        const uint32_t k = base + (threadIdx.x & 63);
-        const bool valid = k < total;
-        PathState ps; ps.o = mk3(0.f, 0.f, 0.f); ps.d = mk3(0.f, 0.f, 1.f); ps.result = ps.o; ps.energy = 1.0f;
-        RayWalk W; walk_idle(W);
-        uint32_t pixel = 0; int bounce = 0;
-        if (valid) suspend_load(Q.records + (size_t)k, pixel, bounce, ps, W, stack);
-        (void)walk_run<false>(S, ps.o, ps.d, stack, W, 64u, 0u);     // rays from everywhere: every lane steps every trip
-        bool again = false;
-        if (valid) {
-            float ndl = 0.0f;
-            const int cont = shade_bounce<false, REFRACT>(S, W.c, ps, bounce, F.lightY, F.lightZ, &ndl);
-            again = cont != 0 && bounce == 0;
-        }
-        if (__ballot(again) != 0) {            // second bounce of the rays that were suspended during their first
-            if (again) walk_begin(S, ps.o, ps.d, W); else walk_idle(W);
-            (void)walk_run<false>(S, ps.o, ps.d, stack, W, 64u, 0u);     // rays from everywhere: every lane steps every trip
-            if (again) { float ndl = 0.0f; (void)shade_bounce<false, REFRACT>(S, W.c, ps, 1, F.lightY, F.lightZ, &ndl); }
-        }
-        if (valid) out[pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
-    }
-}
-
 // ---- wavefront form of Trace: one launch per bounce with ballot compaction in between ----------------
 // The megakernel above runs bounce 1 inside the same wave as bounce 0, at the lane density of the pixels
 // that hit something (31 % on multi-1M) and on top of the wave's bounce-0 latency. Here bounce 0 writes the
@@ -440,7 +352,7 @@ __global__ __launch_bounds__(CRT_BLOCK, COUNT ? CRT_WAVES_PER_SIMD_COUNT : CRT_W
         ps.o = mk3(F.camPos[0], F.camPos[1], F.camPos[2]);
         ps.d = raygen_dir(F, px, py);
         if (COUNT) { lc.rays++; lc.primary++; }
-        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc, F.smallPacket);
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
         cont = shade_bounce(S, c, ps, 0, F.lightY, F.lightZ) != 0;
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[(size_t)py * (size_t)F.width + (size_t)px] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
@@ -479,7 +391,7 @@ __global__ __launch_bounds__(CRT_BLOCK, COUNT ? CRT_WAVES_PER_SIMD_COUNT : CRT_W
         const float4 partial = out[r.pixel];
         ps.result = mk3(partial.x, partial.y, partial.z);
         if (COUNT) { lc.rays++; lc.secondary++; }
-        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc, F.smallPacket);
+        Closest c = closest_hit<COUNT>(S, ps.o, ps.d, stack, lc);
         const bool cont = shade_bounce(S, c, ps, 1, F.lightY, F.lightZ) != 0;
         if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
         out[r.pixel] = make_float4(ps.result.x, ps.result.y, ps.result.z, 1.0f);
@@ -594,14 +506,14 @@ __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD_COUNT) void crt_query
                                                               CrtRayHit* __restrict__ out, unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
-    const CrtStack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
+    const CrtStackT<TLAS ? CRT_TLAS_PARK : 0> stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     const int k = blockIdx.x * CRT_BLOCK + threadIdx.x;
     if (k < n) {
         v3 o = mk3(origins[3 * k], origins[3 * k + 1], origins[3 * k + 2]);
         v3 d = mk3(dirs[3 * k], dirs[3 * k + 1], dirs[3 * k + 2]);
         lc.rays++;
-        Closest c = closest_hit<true, false, false, TLAS>(S, o, d, stack, lc, 16u);
+        Closest c = closest_hit<true, false, false, TLAS>(S, o, d, stack, lc);
         CrtRayHit h;
         if (c.anyHit) { h.t = c.hit.t; h.u = c.hit.u; h.v = c.hit.v; h.triIndex = c.hit.tri; h.instance = c.hitInstance; lc.hits++; }
         else { h.t = c.distance; h.u = 0.0f; h.v = 0.0f; h.triIndex = 0; h.instance = -1; lc.misses++; }

@@ -42,7 +42,6 @@ struct FrameSlot {
     unsigned frames = 0;
     float4* out = nullptr;
     float4* aux = nullptr; size_t auxPixels = 0;   // CRT_RENDER_FXAA: the unfiltered frame the filter reads (allocated on first use)
-    CrtSuspended* susp = nullptr; uint32_t* suspCounters = nullptr; size_t suspCap = 0;   // straggler hand-off queue of this slot (count, head)
     uint32_t* ovf = nullptr; size_t ovfBlocks = 0;   // traversal-stack overflow area of this slot's launches (CrtStack), one block per workgroup
     uint32_t* order = nullptr; uint32_t* len = nullptr; uint32_t* cost = nullptr;   // feedback launch lists
     size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 };
@@ -89,9 +88,6 @@ struct State {
     unsigned long long* counters = nullptr; int* err = nullptr;
     unsigned long long* stamps = nullptr; size_t stampBytes = 0, stampWaves = 0;
     int numCUs = 0;
-    uint32_t suspendAfter = 64;
-    uint32_t suspendAt = CRT_SUSPEND_AT, suspendAtAsync = CRT_SUSPEND_AT;   // straggler hand-off threshold (0 = off), synchronous / pipelined frames
-    uint32_t smallPacket = CRT_SMALL_PACKET, smallPacketAsync = CRT_SMALL_PACKET_ASYNC;   // CrtFrame::smallPacket for synchronous / pipelined frames
     int forceTlas = -1;   // CRT_TLAS=0/1: force the linear / tree candidate search (tests); default: by instance count
     int feedbackAsync = 0; int feedback = 1; int maxSplit = CRT_MAX_SPLIT, maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED;
     // feedback lists while the view changes: rank a tile by max(own cost, costSpread x heaviest of its 8 neighbours) -- next
@@ -187,19 +183,6 @@ int ensure_overflow(FrameSlot& fs, size_t blocks)
     fs.ovf = nullptr; fs.ovfBlocks = 0;
     HIPCHK(hipMalloc(&fs.ovf, blocks * CRT_OVF_WORDS_PER_BLOCK * sizeof(uint32_t)));   // never initialised: entries are written before they are read
     fs.ovfBlocks = blocks;
-    return CRT_OK;
-}
-
-// The straggler queue of a slot holds one record per pixel this device renders (a pixel is suspended at most once).
-int ensure_suspend_queue(FrameSlot& fs, size_t records)
-{
-    if (!fs.suspCounters) { HIPCHK(hipMalloc(&fs.suspCounters, 2 * sizeof(uint32_t))); }
-    if (records <= fs.suspCap) return CRT_OK;
-    HIPCHK(hipStreamSynchronize(fs.stream));
-    if (fs.susp) (void)hipFree(fs.susp);
-    fs.susp = nullptr; fs.suspCap = 0;
-    HIPCHK(hipMalloc(&fs.susp, records * sizeof(CrtSuspended)));
-    fs.suspCap = records;
     return CRT_OK;
 }
 
@@ -545,10 +528,6 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
     g.numCUs = prop.multiProcessorCount;
     { const char* e = getenv("CRT_KERNEL"); g.wavefront = (e && strcmp(e, "wavefront") == 0); }  // default: megakernel (faster)
-    { const char* e = getenv("CRT_SMALL_PACKET"); g.smallPacket = e ? (uint32_t)atoi(e) : (uint32_t)CRT_SMALL_PACKET; }
-    { const char* e = getenv("CRT_SUSPEND_AFTER"); g.suspendAfter = e ? (uint32_t)atoi(e) : 64u; }
-    { const char* e = getenv("CRT_SUSPEND_AT"); g.suspendAt = e ? (uint32_t)atoi(e) : (uint32_t)CRT_SUSPEND_AT; e = getenv("CRT_SUSPEND_AT_ASYNC"); g.suspendAtAsync = e ? (uint32_t)atoi(e) : g.suspendAt; }
-    { const char* e = getenv("CRT_SMALL_PACKET_ASYNC"); g.smallPacketAsync = e ? (uint32_t)atoi(e) : (uint32_t)CRT_SMALL_PACKET_ASYNC; }
     { const char* e = getenv("CRT_SPLIT_BETA"); g.splitBeta = e ? (float)atof(e) : CRT_SPLIT_BETA; }
     { const char* e = getenv("CRT_SPLIT_BETA_ASYNC"); g.splitBetaAsync = e ? (float)atof(e) : CRT_SPLIT_BETA_ASYNC; }
     { const char* e = getenv("CRT_COST_SPREAD"); g.costSpread = e ? (float)atof(e) : 0.8f; }
@@ -584,7 +563,7 @@ static void release_all()
                      g.texels, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount };
     for (FrameSlot& fs : g.slot) {
-        void* q[] = { fs.out, fs.aux, fs.ovf, fs.susp, fs.suspCounters, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
+        void* q[] = { fs.out, fs.aux, fs.ovf, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
         for (void* p : q) if (p) (void)hipFree(p);
         if (fs.staging) (void)hipHostFree(fs.staging);
         if (fs.staged) (void)hipEventDestroy(fs.staged);
@@ -972,28 +951,13 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
             crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
         }
-    } else if (!count && !(flags & CRT_RENDER_SHADOWS) && F.suspendAt > 0 && S.numInstances <= 64 && g.forceTlas != 1) {
-        // plain launch with straggler hand-off: the trace kernel, then the kernel that finishes the suspended rays
-        const bool refract = (flags & CRT_RENDER_REFRACTION) != 0;
-        const size_t records = (size_t)F.ownedTileRows * CRT_TILE * (size_t)F.width;
-        RCCHK(ensure_suspend_queue(fs, records));
-        HIPCHK(hipMemsetAsync(fs.suspCounters, 0, 2 * sizeof(uint32_t), fs.stream));
-        CrtSuspendQueue Q = { fs.susp, fs.suspCounters, fs.suspCounters + 1, (uint32_t)(records > 0xFFFFFFFFull ? 0xFFFFFFFFull : records) };
-        unsigned sgrid = (unsigned)((records + CRT_BLOCK - 1) / CRT_BLOCK);
-        const unsigned resident = (unsigned)g.numCUs * 4u * CRT_WAVES_PER_SIMD / 2u;      // half the machine's wave slots: each wave loops over packets
-        if (sgrid > resident) sgrid = resident;
-        if (sgrid < 1) sgrid = 1;
-        if (refract) { crt_trace_fast_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); crt_straggler_kernel<true><<<sgrid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); }
-        else { crt_trace_fast_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); crt_straggler_kernel<false><<<sgrid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, Q); }
     } else {
         // default megakernel: <COUNT, STAMP, SHADOW, TLAS, REFRACT>
         *epilogueApplied = true;
         const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, refract = (flags & CRT_RENDER_REFRACTION) != 0;
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
         const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
-        const bool allSteps = !count && F.smallPacket >= (uint32_t)CRT_BLOCK;      // frames in flight: the instantiation without the vote
-#define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) do { if (allSteps) crt_trace_kernel<C_, false, S_, T_, R_, !C_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters); \
-                                               else crt_trace_kernel<C_, false, S_, T_, R_, false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters); } while (0)
+#define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) crt_trace_kernel<C_, false, S_, T_, R_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters)
 #define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) CRT_LAUNCH_TRACE3(C_, S_, T_, true); else CRT_LAUNCH_TRACE3(C_, S_, T_, false); } while (0)
 #define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) CRT_LAUNCH_TRACE2(C_, S_, true); else CRT_LAUNCH_TRACE2(C_, S_, false); } while (0)
         if (count) { if (shadow) CRT_LAUNCH_TRACE(true, true); else CRT_LAUNCH_TRACE(true, false); }
@@ -1042,9 +1006,6 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // tail is hidden by the next frame and the lists only cost (cost atomics, the sort launch, quadrant waves at a quarter
     // of the lane utilisation): 7.58 with, 7.72 Gray/s without on multi-1M -> pipelined frames use the plain row-interleaved order.
     if (g.feedback && !g.wavefront && (!pipelined || g.feedbackAsync)) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
-    F.smallPacket = pipelined ? g.smallPacketAsync : g.smallPacket;
-    F.suspendAt = pipelined ? g.suspendAtAsync : g.suspendAt;
-    F.suspendAfter = g.suspendAfter;
     {   // overflow blocks: one per workgroup of the largest launch of this frame (wavefront: the bounce launch may be larger)
         size_t blocks = grid;
         if (g.wavefront) { const size_t g2 = ((size_t)F.ownedTileRows * CRT_TILE * (size_t)F.width + CRT_BLOCK - 1) / CRT_BLOCK; if (g2 > blocks) blocks = g2; }

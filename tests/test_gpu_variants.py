@@ -42,32 +42,6 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     assert not np.array_equal(bits(fused[0]), bits(ref)) and not np.array_equal(bits(fused[2]), bits(fused[0]))
 
 
-@pytest.mark.parametrize("name", ["tiny", "multi-1M", "sponza-sibenik"])
-def test_straggler_hand_off_is_bit_identical(name, monkeypatch):
-    """CRT_SUSPEND_AT=8 (opt-in, crt_trace_fast_kernel + crt_straggler_kernel): the last working lanes of a wave are
-    suspended -- path, running hit, traversal position, candidate instances, stack -- and finished in dense packets by a
-    second kernel. Same pixels as the committed full-size answers (synchronous, pipelined, with refraction)."""
-    import hashlib
-    import json
-    import os
-    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_frames.json")))[name]
-    sc = scenes.get(name)
-    monkeypatch.setenv("CRT_SUSPEND_AT", "8")
-    monkeypatch.setenv("CRT_SUSPEND_AFTER", "16")
-    with driver.Session(gold["width"], gold["height"], device=0) as s:
-        s.load_scene(sc)
-        for flags in (0, 0, 4, 4, 4, 4):
-            s.render_raw(flags)
-        assert hashlib.sha256(np.ascontiguousarray(s.read_output()).tobytes()).hexdigest() == gold["frame_sha256"]
-        s.render_raw(256)
-        with_refraction = s.read_output()
-    monkeypatch.delenv("CRT_SUSPEND_AT")
-    with driver.Session(gold["width"], gold["height"], device=0) as s:
-        s.load_scene(sc)
-        s.render_raw(256)
-        assert np.array_equal(bits(s.read_output()), bits(with_refraction))
-
-
 def test_stamped_launch_renders_the_same_frame():
     """CRT_RENDER_STAMPS (the diagnostic instantiation behind tools/wave_timeline.py: per-wave start/end stamps, 6 waves per
     SIMD) must render the frame the plain launch renders -- also through the per-pixel epilogue (PostProcess, RGBA8 target),

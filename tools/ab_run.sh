@@ -1,15 +1,16 @@
 #!/bin/bash
 # GPU-box side of an A/B: bench every prebuilt variant under build/ab/ (tools/ab_build.sh), restoring the default library
-# afterwards. BENCH_ARGS adds bench.py arguments. Usage: tools/ab_run.sh [name ...]   (default: all)
+# afterwards (also when interrupted). BENCH_ARGS adds bench.py arguments. Usage: tools/ab_run.sh [name ...]   (default: all)
 cd "$(dirname "$0")/.."
 cp clraytracer_amd/csrc/libcrt_hip.so /tmp/libcrt_hip.default.so
+trap 'cp /tmp/libcrt_hip.default.so clraytracer_amd/csrc/libcrt_hip.so' EXIT
 names="$@"; [ -z "$names" ] && names=$(ls build/ab)
 for name in $names; do
+  [ -f build/ab/$name/libcrt_hip.so ] || { echo "[$name] no library (build failed?)" | tee -a gpurun_out/ab_results.txt; continue; }
   cp build/ab/$name/libcrt_hip.so clraytracer_amd/csrc/libcrt_hip.so
-  r=$(timeout -k 10 240 python bench.py --steps ${AB_STEPS:-100} --warmup 10 --no-cpu-baseline $BENCH_ARGS 2>gpurun_out/ab_$name.err | tail -1 | python -c "
+  r=$(timeout -k 10 240 python bench.py --steps ${AB_STEPS:-100} --warmup 10 --no-cpu-baseline --no-extras $BENCH_ARGS 2>gpurun_out/ab_$name.err | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); s=d.get('synchronous_frames',{})
 print(d['value'], d['ms_per_step'], 'sync', s.get('value'), s.get('ms_per_step'))")
   echo "[$name: $(cat build/ab/$name/flags.txt)] Mrays/s, ms/frame: $r" | tee -a gpurun_out/ab_results.txt
 done
-cp /tmp/libcrt_hip.default.so clraytracer_amd/csrc/libcrt_hip.so

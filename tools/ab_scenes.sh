@@ -1,13 +1,15 @@
 #!/bin/bash
-# GPU-box side of an A/B over several scenes: tools/ab_scenes.sh name1 name2 ...  (variants built by tools/ab_build.sh)
+# GPU-box side of an A/B over several scenes: tools/ab_scenes.sh name1 name2 ...  (variants built by tools/ab_build.sh);
+# the default library is restored afterwards (also when interrupted). AB_SCENES overrides the scene list.
 cd "$(dirname "$0")/.."
 cp clraytracer_amd/csrc/libcrt_hip.so /tmp/libcrt_hip.default.so
+trap 'cp /tmp/libcrt_hip.default.so clraytracer_amd/csrc/libcrt_hip.so' EXIT
 for name in "$@"; do
+  [ -f build/ab/$name/libcrt_hip.so ] || { echo "$name | no library (build failed?)" | tee -a gpurun_out/ab_scenes.txt; continue; }
   cp build/ab/$name/libcrt_hip.so clraytracer_amd/csrc/libcrt_hip.so
   line="$name"
-  for sc in multi-1M sponza-sibenik multi-1M-dense nanosuit-demo; do
-    line="$line | $sc $(python bench.py --scene $sc --no-cpu-baseline --no-config5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['synchronous_frames']['value'])")"
+  for sc in ${AB_SCENES:-multi-1M sponza-sibenik multi-1M-dense nanosuit-demo}; do
+    line="$line | $sc $(timeout -k 10 240 python bench.py --scene $sc --no-cpu-baseline --no-extras $BENCH_ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['synchronous_frames']['value'])")"
   done
-  echo "$line"
+  echo "$line" | tee -a gpurun_out/ab_scenes.txt
 done
-cp /tmp/libcrt_hip.default.so clraytracer_amd/csrc/libcrt_hip.so
