@@ -17,13 +17,16 @@ HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
 
 EXAMPLE = examples/crt_headless
 
-UBENCH = tools/ubench/gather
+UBENCH = tools/ubench/gather tools/ubench/chain
 
 all: $(HIP_SO) $(HOST_SO) $(EXAMPLE) $(UBENCH) oracle
 
 # vector-L1 gather microbenchmark (profiles/r01_ubench_gather.txt)
-$(UBENCH): tools/ubench/gather.hip
+tools/ubench/gather: tools/ubench/gather.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
+# dependent-chain 64-B gather microbenchmark: the ceiling bench.py's roofline.chain is taken against (profiles/r03_ubench_chain.*)
+tools/ubench/chain: tools/ubench/chain.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -o $@ $<
 
 # the reference's EngineMain loop over the mirrored C++ API
 $(EXAMPLE): examples/headless_main.cpp $(HOST_SO)

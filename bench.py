@@ -174,8 +174,11 @@ def main():
     ap.add_argument("--shadows", action="store_true", help="extension: one any-hit shadow ray per lit first hit (CRT_RENDER_SHADOWS); not the reference's semantics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the 3840x2160 one-GPU point of the N = 1 line (profiling runs: it launches the same kernel at another size)")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (+ synchronous frames): no config-5 point, no sub-records (A/B runs)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    if args.no_extras:
+        args.no_config5 = True
 
     # stdout carries exactly ONE line (the JSON); anything native libraries print to fd 1 on the way (RCCL's banner)
     # goes to stderr instead

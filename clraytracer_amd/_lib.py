@@ -61,6 +61,10 @@ HIP_API = {
     "crt_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]),
     "crt_init_gpus": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "crt_num_devices": (C.c_int, []),
+    "crt_peer_access": (C.c_int, [C.c_int]),
+    "crt_gather_path": (C.c_char_p, []),
+    "crt_debug_inject_failure": (C.c_int, [C.c_int]),
+    "crt_debug_measure_clock": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "crt_shutdown": (C.c_int, []),
     "crt_resize": (C.c_int, [C.c_int, C.c_int]),
     "crt_set_row_bands": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -103,6 +107,7 @@ HOST_API = {
     "crth_initialize_host_only": (C.c_int, [C.c_int, C.c_int]),
     "crth_terminate": (None, []),
     "crth_last_error": (C.c_int, []),
+    "crth_clear_error": (None, []),
     "crth_prepare_meshes": (None, []),
     "crth_import_texture": (C.c_int, [C.c_char_p]),
     "crth_import_texture_rgb8": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp]),

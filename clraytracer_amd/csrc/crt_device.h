@@ -185,6 +185,9 @@ __device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__us
 
 struct CrtDevInstance;
 struct Triout { float t, u, v; uint32_t tri; };
+// loads through a constant-address-space pointer become scalar loads (s_load_*, scalar cache) when the address is wave-uniform
+typedef float crt_f32x4 __attribute__((ext_vector_type(4)));
+typedef const crt_f32x4 __attribute__((address_space(4)))* crt_const_f32x4_ptr;
 
 struct LaneCounters {
     uint32_t rays, primary, secondary, hits, misses;
@@ -277,6 +280,31 @@ __device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
     return r;
 }
 
+// The device record of instance `inst` (per lane). It comes through a SCALAR load (one s_load_dwordx16 through the scalar
+// cache) when every lane that asks in this step asks for the same instance -- the common case for a coherent packet, whose
+// lanes share their first candidates and mostly hit the same instance -- and through four per-lane vector loads otherwise:
+// vector-memory instructions are what bounds the kernel, and unlike the node fetches (where the same test
+// cost more than it saved, round 2) instance records are fetched rarely enough for one readfirstlane + compare + ballot
+// per step to pay. (The table is written by crt_relayout_instances in an earlier launch, never by the reading kernel.)
+__device__ __forceinline__ CrtDevInstance load_instance(const CrtDevInstance* __restrict__ table, uint32_t inst)
+{
+    CrtDevInstance I;
+#ifndef CRT_NO_SCALAR_ENTER
+    const uint32_t inst0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)inst);
+    if (__ballot(inst != inst0) == 0) {
+        const crt_const_f32x4_ptr p = (crt_const_f32x4_ptr)(table + inst0);
+        const crt_f32x4 a = p[0], b = p[1], c = p[2], e = p[3];
+        I.r0 = make_float4(a.x, a.y, a.z, a.w); I.r1 = make_float4(b.x, b.y, b.z, b.w);
+        I.r2 = make_float4(c.x, c.y, c.z, c.w); I.r3 = make_float4(e.x, e.y, e.z, e.w);
+    } else
+#endif
+    {
+        const CrtDevInstance* ip = table + inst;
+        I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
+    }
+    return I;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-lane traversal state machine: the instance loop + IntersectBVH of kernel_main.cl:124-160,198-217.
 //
@@ -293,6 +321,9 @@ struct Traversal {
     v3 mo, md, inv;               // ray in the current instance's object space (direction not renormalised, hazard H6)
     Triout tr;                    // running best of the current instance (kernel_main.cl:200-202)
     int sp, prot, inters;         // stack pointer, pop counter (kernel_main.cl:131), OR of the `passed` flags
+#ifdef CRT_PREFETCH_FAR
+    uint32_t pf;                  // experiment: destination of the one-dword touch of a pushed child's record
+#endif
     uint32_t ref, curInst;
     bool active;                  // inside an instance
 
@@ -301,6 +332,9 @@ struct Traversal {
         mo = mk3(0.f, 0.f, 0.f); md = mo; inv = mo;
         tr.t = 0.f; tr.u = 0.f; tr.v = 0.f; tr.tri = 0;
         sp = 0; prot = 0; inters = 0; ref = 0; curInst = 0; active = false;
+#ifdef CRT_PREFETCH_FAR
+        pf = 0;
+#endif
     }
     __device__ __forceinline__ bool at_inner() const { return active && !(ref & CRT_LEAF_BIT); }
     __device__ __forceinline__ bool at_leaf() const { return active && (ref & CRT_LEAF_BIT); }
@@ -321,11 +355,15 @@ struct Traversal {
         } else finish(c);
     }
     // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root
+    // The instance record comes through a SCALAR load (one s_load_dwordx16 through the scalar cache) when every lane that
+    // enters an instance in this step enters the same one -- the common case for a coherent packet, whose lanes share their
+    // first candidates -- and through four per-lane vector loads otherwise: vector-memory instructions are what bounds the
+    // kernel, and unlike the node fetches (where the same test cost more than it saved, round 2) entries are rare
+    // enough for one readfirstlane + compare + ballot per entering step to pay.
     __device__ __forceinline__ void enter(const CrtDevScene& S, uint32_t inst, v3 o, v3 d, float bestSoFar, LaneCounters& lc)
     {
         curInst = inst;
-        const CrtDevInstance* ip = S.devInstances + inst;
-        CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
+        const CrtDevInstance I = load_instance(S.devInstances, inst);
         mo = xform_xyz(I, o.x, o.y, o.z, 1.0f);
         md = xform_xyz(I, d.x, d.y, d.z, 0.0f);
         inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);       // native_recip pinned to IEEE
@@ -343,6 +381,9 @@ struct Traversal {
         if (COUNT) lc.innerVisits++;
         float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
         float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
+#ifdef CRT_PREFETCH_FAR
+        asm volatile("" : "+v"(pf));      // the touch issued by an earlier step has landed by now (loads return in order): its register may be reused
+#endif
         uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
         if (dist1 > dist2) {
             float tf = dist1; dist1 = dist2; dist2 = tf;
@@ -355,6 +396,12 @@ struct Traversal {
                 if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
                 stack.write(sp, farRef);
                 sp++;
+#ifdef CRT_PREFETCH_FAR
+                if (!(farRef & CRT_LEAF_BIT)) {      // make the pushed child's record resident before it is popped: one dword of it
+                    const float* q = reinterpret_cast<const float*>(S.pairs + (size_t)farRef * 4);
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf) : "v"(q) : "memory");
+                }
+#endif
                 if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
             }
         }
@@ -372,6 +419,9 @@ struct Traversal {
             inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
             if (ANYHIT) { if (inters) break; }
         }
+#ifdef CRT_PREFETCH_FAR
+        asm volatile("" : "+v"(pf));
+#endif
         if (ANYHIT && inters) finish(c);
         else pop_next(stack, c, lc);
     }
@@ -389,13 +439,19 @@ __device__ __forceinline__ bool sphere_culls(const float4 bs, v3 o, v3 d, float 
 // Conservative candidate mask for instances [base, base + cnt): bit k is cleared only when the ray provably misses
 // instance base+k's bounding sphere (any NaN -> candidate). A culled instance costs upstream exactly one pop and one
 // inner visit and changes nothing, which is what the counters record for it. Wave-uniform loop, scalar loads.
+// The bounding spheres are read through a constant-address-space pointer: the index is wave-uniform, and only for that
+// address space does the compiler turn a uniform load into a SCALAR load (s_load_dwordx4, scalar cache). Through the plain
+// pointer -- a member of a by-value kernel argument carries no noalias/readonly information -- rounds 1-2 issued one VECTOR
+// load per instance, bounce and wave here: 12 % of the trace kernel's vector-memory instructions, on the pipeline that
+// bounds it. The table is written by the host before the launch and never by a kernel.
 template <bool COUNT, bool DEFER_COUNT = false>
 __device__ __forceinline__ unsigned long long candidate_mask(const CrtDevScene& S, v3 o, v3 d, uint32_t base, uint32_t cnt, LaneCounters& lc)
 {
     const float dd = dot3(d, d);
     unsigned long long cand = 0;
+    const crt_const_f32x4_ptr bounds = (crt_const_f32x4_ptr)S.instBounds;
     for (uint32_t k = 0; k < cnt; ++k) {
-        const float4 bs = S.instBounds[base + k];
+        const crt_f32x4 bs = bounds[base + k];
         const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);
         const float oc2 = dot3(oc, oc), b = dot3(oc, d);
         const float r2 = bs.w * bs.w * 1.0201f + 4e-6f * oc2;       // 1 % on the radius + slack growing with distance
@@ -631,8 +687,9 @@ __device__ __forceinline__ int shade_bounce(const CrtDevScene& S, const Closest&
 {
     const float UcharToFloat01 = 1.0f / 255.0f;
     if (c.distance > 99998.0f) {
-        const CrtTexture sky = S.textures[2];
-        int idx = clamp_texel(sample_skybox(ps.d, sky.width, sky.height), S.numTexels);
+        // textures[2] for every lane: a scalar load (constant address space, see crt_const_f32x4_ptr)
+        const crt_f32x4 skyHdr = ((crt_const_f32x4_ptr)S.textures)[2];
+        int idx = clamp_texel(sample_skybox(ps.d, __float_as_int(skyHdr.x), __float_as_int(skyHdr.y)), S.numTexels);
         uint32_t px = S.texels[idx];
         v3 skyc = scale3(mk3((float)(px & 0xffu), (float)((px >> 8) & 0xffu), (float)((px >> 16) & 0xffu)), UcharToFloat01);
         ps.result = add3(ps.result, scale3(skyc, ps.energy));
@@ -641,8 +698,7 @@ __device__ __forceinline__ int shade_bounce(const CrtDevScene& S, const Closest&
     const v3 light = bounce == 0 ? mk3(0.0f, lightY, lightZ) : ps.d;     // lightDir = ray.direction after the first bounce
     const v3 atm0 = scale3(mk3(0.255f, 0.25f, 0.27f), 1.0f);
     const v3 atm = bounce == 0 ? atm0 : scale3(atm0, 0.4f);
-    const CrtDevInstance* ip = S.devInstances + c.hitInstance;
-    CrtDevInstance I; I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
+    const CrtDevInstance I = load_instance(S.devInstances, (uint32_t)c.hitInstance);
     // meshRay of the winning instance, recomputed with the same arithmetic as in the loop
     const v3 mo = xform_xyz(I, ps.o.x, ps.o.y, ps.o.z, 1.0f);
     const v3 md = xform_xyz(I, ps.d.x, ps.d.y, ps.d.z, 0.0f);

@@ -970,7 +970,14 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
     return CRT_OK;
 }
 
-int crt1_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags)
+// In a multi-device session the dispatcher (crt_render) decides once per frame what every device must agree on and hands it
+// to each device's crt1_render: the frame slot (so a device that owned no rows of some frame, or failed one, cannot fall out
+// of step with the primary's slot rotation) and whether the call may return before the device has finished (secondaries
+// never wait on the host: the primary's end-of-frame event waits for their partDone events, which is what gives a
+// synchronous N-device frame the duration of the longest share instead of the sum of two).
+struct RenderPlan { int slot; bool noHostWait; };
+
+int crt1_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags, const RenderPlan* plan = nullptr)
 {
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!args || !invView || !invProj) return CRT_E_BAD_ARGUMENT;
@@ -978,7 +985,16 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
     int rc = CRT_OK;
     CrtFrame F; fill_frame(F, args, invView, invProj);
-    if (F.gridBlocks == 0) return CRT_OK;
+    if (F.gridBlocks == 0) {
+        // a device that owns no rows of this frame still takes part in the frame's hand-shake: its "bands have arrived"
+        // event is recorded on the planned slot so the primary's wait refers to this frame, not to an older one
+        if (plan && g.groupSize > 1 && g.primary != G && plan->slot >= 0 && plan->slot < g.nSlots) {
+            FrameSlot& efs = g.slot[plan->slot];
+            if (plan->slot != 0) g.othersBusy = true;
+            HIPCHK(hipEventRecord(efs.partDone, efs.stream));
+        }
+        return CRT_OK;
+    }
     unsigned grid = (unsigned)F.gridBlocks;
 
     // Slot choice: plain ASYNC frames of the default kernel rotate over the frame slots so consecutive frames
@@ -991,7 +1007,11 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
                         && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
     int slot = 0;
-    if (pipelined) slot = (int)(g.asyncSeq++ % (unsigned)g.nSlots);
+    if (plan) {                              // multi-device session: the dispatcher chose the slot for every device
+        slot = pipelined ? plan->slot : 0;
+        if (slot < 0 || slot >= g.nSlots) return CRT_E_BAD_ARGUMENT;
+        if (!pipelined) { rc = quiesce(); if (rc) return rc; }
+    } else if (pipelined) slot = (int)(g.asyncSeq++ % (unsigned)g.nSlots);
     else { rc = quiesce(); if (rc) return rc; }
     FrameSlot& fs = g.slot[slot];
     EventSet& es = fs.es[fs.frames & 1u];
@@ -1153,7 +1173,49 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     if (isPrimary) HIPCHK(hipEventRecord(fs.slotDone, fs.stream));
     // the reference's clFinish (Renderer.cpp:367): wait for the frame's end event -- the sort for the next frame that is
     // queued behind it needs no waiting for
-    if (!(flags & CRT_RENDER_ASYNC)) HIPCHK(hipEventSynchronize(es.evPost ? es.ev[3] : es.ev[2]));
+    if (!(flags & CRT_RENDER_ASYNC) && !(plan && plan->noHostWait)) HIPCHK(hipEventSynchronize(es.evPost ? es.ev[3] : es.ev[2]));
+    return CRT_OK;
+}
+
+// Whether a frame with these flags rotates over the frame slots (the rule of crt1_render, for the dispatcher)
+static bool frame_is_pipelined(int flags)
+{
+    return (flags & CRT_RENDER_ASYNC) && !g.wavefront && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
+}
+
+// Diagnostic: the shader clock under whatever load the device carries right now. One wave per XCD spins for `micros`
+// microseconds of the 100 MHz real-time counter and reports delta s_memtime / delta s_memrealtime (MI355X_MICROARCH.md, DVFS
+// item 6); runs on a stream of its own, next to the frames in flight.
+__global__ void crt_clock_probe_kernel(unsigned long long ticks, double* __restrict__ out)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0, guard = 0;
+    while (r1 - r0 < ticks && guard < (1ull << 24)) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); ++guard; }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) out[blockIdx.x] = r1 > r0 ? (double)(c1 - c0) / (double)(r1 - r0) * 0.1 : 0.0;
+}
+
+int crt1_debug_measure_clock(int micros, double* ghz)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!ghz || micros < 1 || micros > 100000) return CRT_E_BAD_ARGUMENT;
+    double* d = nullptr; hipStream_t st = nullptr;
+    HIPCHK(hipMalloc(&d, 8 * sizeof(double)));
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    double h[8] = { 0 };
+    if (e == hipSuccess) {
+        crt_clock_probe_kernel<<<8, 64, 0, st>>>((unsigned long long)micros * 100ull, d);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return (int)e;
+    double sum = 0; int n = 0;
+    for (double v : h) if (v > 0.0) { sum += v; ++n; }
+    *ghz = n ? sum / n : 0.0;
     return CRT_OK;
 }
 
@@ -1422,6 +1484,12 @@ struct Group {
     State* dev[CRT_MAX_DEVICES] = { nullptr };
     int hipDevice[CRT_MAX_DEVICES] = { 0 };
     Worker* worker[CRT_MAX_DEVICES] = { nullptr };
+    // how device d's bands reach the primary's frame: 2 = same physical GPU as the primary (rehearsal), 1 = peer mapping
+    // (hipDeviceEnablePeerAccess: xGMI), 0 = no peer access, the runtime stages the copy through host memory
+    int peer[CRT_MAX_DEVICES] = { 0 };
+    unsigned seq = 0;                           // frame-slot rotation of the session (crt_render)
+    bool broken = false;                        // a resize failed on some device and could not be rolled back
+    int injectFailure = -1;                     // crt_debug_inject_failure
 } M;
 
 // selects device d of the session for the calling thread; the primary is re-selected when the scope ends
@@ -1445,7 +1513,8 @@ static void destroy_group()
         release_all();
         delete M.dev[d]; M.dev[d] = nullptr;
     }
-    G = nullptr; M.n = 0;
+    G = nullptr; M.n = 0; M.seq = 0; M.broken = false; M.injectFailure = -1;
+    for (int& p : M.peer) p = 0;
 }
 
 // pure: the block list a rank's gather / read-back copies (needs no device; tests/test_distributed.py)
@@ -1457,11 +1526,20 @@ int crt_band_plan(int height, int bandRows, int rank, int nRanks, int out[4])
     return CRT_OK;
 }
 
+// More than four frame slots want one hardware queue per slot stream; the HIP runtime reads GPU_MAX_HW_QUEUES when it starts
+// (its first call in the process), so this must run before any HIP call: both initialisers call it first. A caller that
+// has already used HIP (e.g. through another library) must export the variable itself.
+static void raise_hw_queues()
+{
+    const char* e = getenv("CRT_FRAMES_IN_FLIGHT");
+    if (e && atoi(e) > 4) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+
 int crt_init_devices(const int* devices, int numDevices, int width, int height)
 {
     if (M.n != 0) return CRT_E_BAD_ARGUMENT;
     if (!devices || numDevices < 1 || numDevices > CRT_MAX_DEVICES) return CRT_E_BAD_ARGUMENT;
-    { const char* e = getenv("CRT_FRAMES_IN_FLIGHT"); if (e && atoi(e) > 4) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }   // read by the HIP runtime at its first call
+    raise_hw_queues();
     int rc = CRT_OK;
     M.n = numDevices;
     for (int d = 0; d < numDevices && rc == CRT_OK; ++d) {
@@ -1469,14 +1547,24 @@ int crt_init_devices(const int* devices, int numDevices, int width, int height)
         M.dev[d] = new State();
         G = M.dev[d];
         rc = init_impl(devices[d], width, height);           // selects the HIP device
+        M.peer[d] = 2;
         if (rc == CRT_OK && numDevices > 1) {
             g.bandRows = 16; g.rank = d; g.nRanks = numDevices;
             g.primary = M.dev[0]; g.groupSize = numDevices;
             if (d > 0 && devices[d] != devices[0]) {
-                // peer copies into the primary's frame and cross-device event waits
+                // the gather copies this device's bands into the primary's frame from this device's stream: it needs the
+                // primary's memory mapped here (xGMI peer access). Without it the runtime stages every copy through host
+                // memory -- correct but slow, so the state is recorded (crt_peer_access) and reported once.
                 int can = 0;
                 (void)hipDeviceCanAccessPeer(&can, devices[d], devices[0]);
-                if (can) { const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = (int)e; (void)hipGetLastError(); }
+                M.peer[d] = 0;
+                if (can) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                    if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) M.peer[d] = 1; else rc = (int)e;
+                    (void)hipGetLastError();
+                }
+                if (M.peer[d] == 0 && rc == CRT_OK)
+                    fprintf(stderr, "crt_init_devices: device %d has no peer access to device %d: its bands are gathered through host memory\n", devices[d], devices[0]);
             }
         }
     }
@@ -1493,6 +1581,7 @@ int crt_init(int device, int width, int height) { return crt_init_devices(&devic
 
 int crt_init_gpus(int numGpus, int width, int height)
 {
+    raise_hw_queues();                          // before the first call that can start the HIP runtime
     int have = 0;
     if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return CRT_E_NO_DEVICE;
     if (numGpus < 1 || numGpus > have || numGpus > CRT_MAX_DEVICES) return CRT_E_BAD_ARGUMENT;
@@ -1502,6 +1591,16 @@ int crt_init_gpus(int numGpus, int width, int height)
 }
 
 int crt_num_devices(void) { return M.n; }
+int crt_peer_access(int device) { if (M.n == 0) return CRT_E_NOT_INITIALIZED; if (device < 0 || device >= M.n) return CRT_E_BAD_ARGUMENT; return M.peer[device]; }
+const char* crt_gather_path(void)
+{
+    if (M.n <= 1) return "none (one device)";
+    int lo = 2;
+    for (int d = 1; d < M.n; ++d) if (M.peer[d] < lo) lo = M.peer[d];
+    return lo == 2 ? "same-device copies (rehearsal: one GPU listed several times)" : (lo == 1 ? "xgmi-peer" : "host-staged");
+}
+int crt_debug_inject_failure(int device) { NEED_SESSION(); if (device < 0 || device >= M.n) return CRT_E_BAD_ARGUMENT; M.injectFailure = device; return CRT_OK; }
+int crt_debug_measure_clock(int micros, double* ghz) { ON_PRIMARY(crt1_debug_measure_clock(micros, ghz)); }
 
 int crt_shutdown(void)
 {
@@ -1512,7 +1611,21 @@ int crt_shutdown(void)
 
 const char* crt_device_name(void) { if (M.n == 0) return ""; Use u(0); return crt1_device_name(); }
 
-int crt_resize(int width, int height) { ON_ALL(crt1_resize(width, height)); }
+int crt_resize(int width, int height)
+{
+    NEED_SESSION();
+    if (M.n == 1) { Use u(0); return crt1_resize(width, height); }
+    // all devices or none: a device that cannot reallocate its frame buffers sends the others back to the old size; if that
+    // fails too the devices disagree about the frame and the session refuses to render (crt_shutdown is what is left)
+    int oldW, oldH;
+    { Use u(0); oldW = g.width; oldH = g.height; }
+    int rc = CRT_OK, done = 0;
+    for (; done < M.n && rc == CRT_OK; ++done) { Use u(done); rc = (done == M.injectFailure) ? (int)CRT_E_UNSUPPORTED : crt1_resize(width, height); }
+    if (M.injectFailure >= 0) M.injectFailure = -1;
+    if (rc == CRT_OK) return CRT_OK;
+    for (int d = 0; d < done - 1; ++d) { Use u(d); if (crt1_resize(oldW, oldH) != CRT_OK) M.broken = true; }
+    return rc;
+}
 int crt_set_row_bands(int bandRows, int rank, int nRanks)
 {
     NEED_SESSION();
@@ -1539,18 +1652,35 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
 {
     NEED_SESSION();
     if (M.n == 1) { Use u(0); return crt1_render(args, invView, invProj, flags); }
+    if (M.broken) return CRT_E_BAD_ARGUMENT;                 // a failed resize left the devices at different frame sizes
     if (!args || !invView || !invProj) return CRT_E_BAD_ARGUMENT;
     if (flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_STAMPS)) return CRT_E_UNSUPPORTED;   // single-device diagnostics
-    // secondaries first, each on its own worker thread (they record the events the primary's stream then waits on);
-    // their copy of the frame never leaves the device except through the gather, so READBACK is the primary's business
-    struct Job { CrtTraceArgs a; float iv[16], ip[16]; int flags; } job;
-    job.a = *args; memcpy(job.iv, invView, 64); memcpy(job.ip, invProj, 64); job.flags = flags & ~CRT_RENDER_READBACK;
-    for (int d = 1; d < M.n; ++d) M.worker[d]->post([job]() { return crt1_render(&job.a, job.iv, job.ip, job.flags); });
+    // The dispatcher decides the frame slot once for every device (the devices' own rotation counters are not used in a
+    // session: a device that owns no rows of a short frame, or whose submission failed, stays in step).
+    RenderPlan plan;
+    { Use u(0); plan.slot = frame_is_pipelined(flags) ? (int)(M.seq++ % (unsigned)g.nSlots) : 0; }
+    plan.noHostWait = true;
+    // secondaries first, each on its own worker thread (they record the events the primary's stream then waits on) and
+    // without waiting for their devices; their copy of the frame never leaves the device except through the gather, so
+    // READBACK is the primary's business
+    struct Job { CrtTraceArgs a; float iv[16], ip[16]; int flags; RenderPlan plan; } job;
+    job.a = *args; memcpy(job.iv, invView, 64); memcpy(job.ip, invProj, 64); job.flags = flags & ~CRT_RENDER_READBACK; job.plan = plan;
+    const int failDevice = M.injectFailure;                  // test hook (crt_debug_inject_failure): that device's submission fails once
+    M.injectFailure = -1;
+    for (int d = 1; d < M.n; ++d) {
+        if (d == failDevice) M.worker[d]->post([]() { return (int)CRT_E_UNSUPPORTED; });
+        else M.worker[d]->post([job]() { return crt1_render(&job.a, job.iv, job.ip, job.flags, &job.plan); });
+    }
     int rc = CRT_OK;
     for (int d = 1; d < M.n; ++d) { const int r = M.worker[d]->wait(); if (r != CRT_OK && rc == CRT_OK) rc = r; }
+    // A secondary failed: its bands will not arrive, so the primary must not queue a wait for them (it would wait on the
+    // slot's previous frame's event and present a frame with stale bands as complete). The frame is abandoned: the error
+    // is returned, nothing of it is readable, and the slot rotation has advanced on every device alike.
+    if (rc != CRT_OK) return rc;
+    if (failDevice == 0) return CRT_E_UNSUPPORTED;
     Use u(0);
-    const int r0 = crt1_render(args, invView, invProj, flags);
-    return rc != CRT_OK ? rc : r0;
+    plan.noHostWait = false;
+    return crt1_render(args, invView, invProj, flags, &plan);
 }
 
 int crt_sync(void) { ON_ALL(crt1_sync()); }

@@ -55,6 +55,7 @@ void Renderer::SetUnorm8(bool enabled) { unorm8 = enabled; }
 void Renderer::SetPipelined(bool enabled) { pipelined = enabled; }
 void Renderer::SetTime(float seconds) { timeSeconds = seconds; }
 int Renderer::LastError() { return lastError ? lastError : ResourceManager::LastError(); }
+void Renderer::ClearError() { lastError = 0; }
 float Renderer::LastFrameMs() { return deviceReady ? crt_last_kernel_ms(0) : -1.0f; }
 
 static int initialize_common(int rc, int width, int height)
@@ -85,7 +86,7 @@ int Renderer::InitializeDevices(const int* devices, int numDevices, int width, i
 void Renderer::OnWindowResize(int width, int height)
 {
     if (width < 16 || height < 16) return;
-    if (deviceReady) check(crt_resize(width, height), "crt_resize");
+    if (deviceReady && !check(crt_resize(width, height), "crt_resize")) return;   // a failed resize leaves the old frame size (and projection) in place
     camera.RecalculateProjection(width, height);
 }
 

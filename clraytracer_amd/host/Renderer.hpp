@@ -47,7 +47,8 @@ namespace Renderer
     void SetRowBands(int bandRows, int rank, int nRanks); // multi-GPU image tiling
     const float* MapOutput();             // host copy of the float4 frame (width*height*4), valid until next Render
     float LastFrameMs();                  // HIP-event time of the last frame's kernels
-    int LastError();
+    int LastError();                      // first error since Initialize / ClearError (errors are returned as codes, not exit(0): DESIGN.md 8)
+    void ClearError();
 }
 
 extern uint g_NumMeshInstances;

@@ -34,6 +34,7 @@ int crth_initialize_host_only(int width, int height)
 
 void crth_terminate(void) { if (hostOnly) ResourceManager::Finalize(); else Renderer::Terminate(); hostOnly = false; }
 int crth_last_error(void) { return hostOnlyError ? hostOnlyError : Renderer::LastError(); }
+void crth_clear_error(void) { Renderer::ClearError(); }
 
 void crth_prepare_meshes(void) { ResourceManager::PrepareMeshes(); }
 int crth_import_texture(const char* path) { return ResourceManager::ImportTexture(path); }

@@ -83,6 +83,12 @@ int crt_init(int device, int width, int height);
 int crt_init_devices(const int* devices, int numDevices, int width, int height);
 int crt_init_gpus(int numGpus, int width, int height);        /* devices 0 .. numGpus-1 */
 int crt_num_devices(void);                                    /* 0 = no session */
+/* How device `device` of the session (0 = the primary) delivers its bands into the primary's frame: 2 = it is the same
+ * physical GPU as the primary (a rehearsal session), 1 = peer mapping enabled (hipDeviceEnablePeerAccess: xGMI), 0 = no peer
+ * access -- the HIP runtime stages every gather copy through host memory (correct, slow; crt_init_devices says so once on
+ * stderr). crt_gather_path() names the slowest path any device of the session uses: "xgmi-peer", "host-staged", ... */
+int crt_peer_access(int device);
+const char* crt_gather_path(void);
 /* Renderer.cpp:377-394, ResourceManager.cpp:303-319 */
 int crt_shutdown(void);
 /* Renderer.cpp:198-211: ignores sizes below 16 like the reference (returns CRT_OK, no change). */
@@ -129,7 +135,8 @@ int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count);
  * invView / invProj are the camera's inverse matrices, row-major (hazard H10: taken as inputs).
  * Frames in flight (no reference counterpart): consecutive CRT_RENDER_ASYNC frames rotate over three frame
  * slots (CRT_FRAMES_IN_FLIGHT=1..8 in the environment, default 3; more than four also wants GPU_MAX_HW_QUEUES=8, which
- * crt_init_devices sets when the HIP runtime has not started yet), each with its own HIP stream, output buffer and
+ * crt_init_devices / crt_init_gpus set before their first HIP call -- effective only if nothing in the process has started the
+ * HIP runtime before; otherwise export it yourself), each with its own HIP stream, output buffer and
  * launch lists, so frames run concurrently and the long-ray tail of one is hidden behind the others; the call
  * blocks only to keep at most two frames queued per slot. Mesh / texture / material uploads, resize, queries and reads
  * wait for every frame in flight first; instance uploads do not need to (see crt_upload_instances). Either way scene
@@ -181,6 +188,13 @@ int crt_get_culled_visits(uint64_t* out);
  * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer / enter-instance / descent loops,
  * leaf trips << 32 | lane-level node visits}. Pass dst = NULL to query the wave count. */
 int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves);
+/* Diagnostic: the shader clock (GHz) the device holds under whatever load it carries while the call runs: one wave per XCD
+ * watches s_memtime against the 100 MHz s_memrealtime for `micros` microseconds on a stream of its own (bench.py calls it
+ * beside frames in flight so that cycle-based figures use the measured clock, not the 2.4 GHz nominal one). */
+int crt_debug_measure_clock(int micros, double* ghz);
+/* Test hook (multi-device sessions): the next crt_render / crt_resize fails on session device `device` as if that
+ * device's submission had returned an error, once. Exercises the "a secondary failed" paths of the dispatcher. */
+int crt_debug_inject_failure(int device);
 
 const char* crt_error_string(int code);
 const char* crt_device_name(void);

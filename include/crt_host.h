@@ -21,6 +21,7 @@ int crth_initialize_devices(const int* devices, int numDevices, int width, int h
 int crth_initialize_host_only(int width, int height);
 void crth_terminate(void);                                   /* Renderer::Terminate */
 int crth_last_error(void);
+void crth_clear_error(void);                 /* Renderer::ClearError: forget a reported Renderer error (e.g. a refused resize) */
 
 void crth_prepare_meshes(void);                              /* ResourceManager::PrepareMeshes */
 int crth_import_texture(const char* path);                   /* ResourceManager::ImportTexture */

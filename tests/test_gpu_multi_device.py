@@ -131,3 +131,111 @@ def test_two_real_devices():
         assert np.array_equal(bits(s.output()), bits(ref))
         s.render_raw(8)
         assert s.counters() == ref_cnt
+
+
+def _render(s, flags):
+    a, iv, ip = s.trace_args()
+    fp = C.POINTER(C.c_float)
+    return s.hip.crt_render(C.byref(a), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), flags)
+
+
+def test_peer_access_state_is_reported():
+    """crt_peer_access / crt_gather_path: how each device's bands reach the primary (a rehearsal session: the same GPU)."""
+    sc = scenes.get("tiny")
+    hip = _lib.hip()
+    with driver.Session(256, 144, devices=[0, 0, 0]) as s:
+        s.load_scene(sc)
+        assert [hip.crt_peer_access(d) for d in range(3)] == [2, 2, 2]
+        assert hip.crt_peer_access(3) < 0 and b"same-device" in hip.crt_gather_path()
+    with driver.Session(256, 144, device=0) as s:
+        assert hip.crt_peer_access(0) == 2 and b"one device" in hip.crt_gather_path()
+
+
+@pytest.mark.parametrize("flags", [0, 4])
+def test_a_failing_secondary_fails_the_frame_and_the_session_recovers(flags):
+    """If a secondary device's submission fails, crt_render returns the error WITHOUT queueing the primary's wait for that
+    device's bands (it would otherwise wait on the slot's previous frame's event and present stale bands as a finished
+    frame). The slot rotation advances on every device alike, so the following frames are whole and correct again."""
+    sc = scenes.get("tiny")
+    w, h = 328, 200
+    ref, _ = single_frame(sc, w, h, flags=0)
+    hip = _lib.hip()
+    with driver.Session(w, h, devices=[0, 0, 0]) as s:
+        s.load_scene(sc)
+        for _ in range(4):
+            assert _render(s, flags) == 0
+        for bad in (1, 2, 0):
+            assert hip.crt_debug_inject_failure(bad) == 0
+            assert _render(s, flags) != 0                      # the frame is abandoned, the error reported
+            for _ in range(5):                                 # ... and every slot is usable again
+                assert _render(s, flags) == 0
+                assert np.array_equal(bits(s.read_output()), bits(ref))
+        assert hip.crt_debug_inject_failure(7) != 0
+
+
+def test_failed_resize_rolls_every_device_back():
+    """crt_resize on a session is all-or-nothing: when one device cannot reallocate, the devices that already did go back to
+    the old size, the error is returned and the session keeps rendering the old frame size."""
+    sc = scenes.get("tiny")
+    w, h = 328, 200
+    ref, _ = single_frame(sc, w, h, flags=0)
+    hip = _lib.hip()
+    with driver.Session(w, h, devices=[0, 0, 0]) as s:
+        s.load_scene(sc)
+        assert hip.crt_debug_inject_failure(2) == 0
+        with pytest.raises(driver.CrtError):
+            s.resize(640, 360)                                 # Renderer::OnWindowResize -> crt_resize fails on device 2
+        s.h.crth_clear_error()
+        assert _render(s, 0) == 0                              # still w x h on every device (and the old projection)
+        assert np.array_equal(bits(s.read_output()), bits(ref))
+        s.resize(640, 360)                                     # a later resize goes through
+        assert _render(s, 0) == 0
+        got = s.read_output()
+    ref2, _ = single_frame(sc, 640, 360, flags=0)
+    assert np.array_equal(bits(got), bits(ref2))
+
+
+def test_devices_without_rows_stay_in_step():
+    """A frame so short that some devices own no rows of it (16 rows = one band) must not let those devices fall out of the
+    slot rotation: after pipelined short frames and a resize to a taller frame, every band of every later frame is there."""
+    sc = scenes.get("tiny")
+    with driver.Session(64, 16, devices=[0, 0, 0]) as s:
+        s.load_scene(sc)
+        for _ in range(4):                                     # devices 1 and 2 own nothing here
+            assert _render(s, 4) == 0
+        short = s.read_output()
+        s.resize(328, 200)
+        s.set_camera(sc.camera_pos, sc.camera_front)
+        frames = []
+        for _ in range(5):                                     # not a multiple of the slot count
+            assert _render(s, 4) == 0
+            frames.append(s.read_output())
+    ref_short, _ = single_frame(sc, 64, 16, flags=0)
+    ref, _ = single_frame(sc, 328, 200, flags=0)
+    assert np.array_equal(bits(short), bits(ref_short))
+    for k, f in enumerate(frames):
+        assert np.array_equal(bits(f), bits(ref)), k
+
+
+def test_synchronous_frame_overlaps_the_devices_shares():
+    """Renderer::Render() semantics on N devices: the secondaries must not be waited for on the host before the primary's
+    share is submitted (that made a synchronous frame last T_secondary + T_primary). Rehearsed on one GPU the shares
+    compete for the same device, so the check is lenient: a 2-state synchronous frame of a tail-bound scene must take
+    clearly less than two single-device frames (each half-frame keeps the full frame's longest rays)."""
+    import time
+    sc = scenes.get("multi-1M")
+    w, h = 1920, 1080
+
+    def sync_ms(devices):
+        with driver.Session(w, h, devices=devices) if devices else driver.Session(w, h, device=0) as s:
+            s.load_scene(sc)
+            for _ in range(10):
+                assert _render(s, 0) == 0
+            t0 = time.perf_counter()
+            for _ in range(40):
+                assert _render(s, 0) == 0
+            return (time.perf_counter() - t0) / 40 * 1e3
+    one = sync_ms(None)
+    two = sync_ms([0, 0])
+    print(f"synchronous frame: one device state {one:.3f} ms, two states on the same GPU {two:.3f} ms")
+    assert two < 1.6 * one, (one, two)

@@ -1,0 +1,211 @@
+// Microbenchmark: the ceiling of DEPENDENT 64-byte record gathers on gfx950 -- what binds crt_trace_kernel.
+//
+// Every lane of every wave chases its own chain through a table of 64-B child-pair records laid out like the trace kernel's
+// `pairs` array {L.min,L.ref | L.max,- | R.min,R.ref | R.max,-}: fetch the record (4 x global_load_dwordx4), run the inner
+// step's arithmetic on it (two slab tests against the lane's ray = IntersectAABB of kernel_main.cl:108-117, near/far
+// ordering, an LDS stack push), and follow the nearer child's reference -- the next address is known only when that
+// arithmetic is done, exactly as in Traversal::inner (clraytracer_amd/csrc/crt_device.h). No leaves, no shading, no idle
+// lanes, no tails: the chip is full of chains for the whole launch (8 waves per SIMD x 64 lanes = the trace kernel's
+// occupancy), so records per cycle per CU here is the rate that chain shape can reach at a given cache-hit mix.
+//
+// The hit mix is built into the table: a child reference points into a HOT region (128 records, resident in every CU's
+// 32 KiB vector L1), a WARM region (1 MiB: misses L1, resident in every XCD's 4 MiB L2) or a COLD region (128 MiB: misses L2,
+// resident in the 256 MiB Infinity Cache) with probabilities chosen per run. The trace kernel's measured mix on multi-1M
+// (profiles/r02_summary.md: 89 % of vector L1 line accesses hit; a record is 4 accesses of which the last 3 always hit, so
+// 44 % of the RECORDS miss L1; 72 % of L1 misses hit L2) is hot 0.56 / warm 0.317 / cold 0.123.
+//
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o chain chain.hip && ./chain [json-path]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define HOT_RECS 128u
+#define WARM_RECS (1u << 14)      // 1 MiB
+#define COLD_RECS (1u << 21)      // 128 MiB
+#define TOTAL_RECS (HOT_RECS + WARM_RECS + COLD_RECS)
+
+struct Rng { uint64_t s; uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); } float unit() { return (float)(next() & 0xFFFFFF) / 16777216.0f; } };
+
+static uint32_t pick(Rng& r, float pHot, float pWarm)
+{
+    const float u = r.unit();
+    if (u < pHot) return r.next() % HOT_RECS;
+    if (u < pHot + pWarm) return HOT_RECS + r.next() % WARM_RECS;
+    return HOT_RECS + WARM_RECS + r.next() % COLD_RECS;
+}
+
+// the inner step of the trace kernel, on a record of the same layout
+__device__ __forceinline__ float slab(float ox, float oy, float oz, float ix, float iy, float iz, float4 bmin, float4 bmax, float minSoFar)
+{
+    float tminx = (bmin.x - ox) * ix, tminy = (bmin.y - oy) * iy, tminz = (bmin.z - oz) * iz;
+    float tmaxx = (bmax.x - ox) * ix, tmaxy = (bmax.y - oy) * iy, tmaxz = (bmax.z - oz) * iz;
+    float tnear = fmaxf(fmaxf(fminf(tminx, tmaxx), fminf(tminy, tmaxy)), fminf(tminz, tmaxz));
+    float tfar = fminf(fminf(fmaxf(tminx, tmaxx), fmaxf(tminy, tmaxy)), fmaxf(tminz, tmaxz));
+    return (tnear < tfar && tnear > 0.0f && tnear < minSoFar) ? tnear : 1e30f;
+}
+
+// stamps[wave] = {s_memrealtime start, end, s_memtime cycles}
+// LOADS: dwordx4 loads per record (4 = the whole 64-B record as the trace kernel reads it; 1 and 2 are diagnostics that read only
+// the first 16 / 32 bytes and reuse them: is the cost per instruction or per record?). SHARE: lanes that walk the same chain
+// (1 = every lane its own; 4 = groups of four neighbouring lanes share a ray and therefore every record: is the cost per lane
+// or per distinct record?)
+// KIND: 0 = global_load_dwordx4 (the trace kernel's), 1 = buffer_load_dwordx4 with a 32-bit per-lane offset (offen) against an
+// SGPR buffer resource, 2 = global_load_dwordx2 (8 of every 16 bytes), 3 = global_load_dword (4 of every 16 bytes): is the fixed
+// cost of a vector load its address (64 x 64-bit addresses) or its data (64 x 16 B)?
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int KIND>
+__device__ __forceinline__ float4 load16(const float4* __restrict__ recs, __amdgpu_buffer_rsrc_t rsrc, uint32_t idx16)
+{
+    if (KIND == 1) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx16 * 16u), 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    } else if (KIND == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(recs + idx16);
+        return make_float4(v.x, v.y, v.x + 0.1f, v.y);
+    } else if (KIND == 3) {
+        const float v = *reinterpret_cast<const float*>(recs + idx16);
+        return make_float4(v, v + 0.2f, v + 0.1f, v);
+    }
+    return recs[idx16];
+}
+template <int LOADS, int SHARE, int KIND = 0>
+__global__ __launch_bounds__(64, 8) void chain_kernel(const float4* __restrict__ recs, int hops, uint32_t activeLanes, uint32_t* __restrict__ out,
+                                                      unsigned long long* __restrict__ stamps)
+{
+    __shared__ uint32_t s_stack[20 * 64];      // the trace kernel's 5 KiB per wave: 32 waves fill the CU's 160 KiB
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    uint32_t acc = 0;
+    if (lane < activeLanes) {
+        uint32_t h = (wave * 64u + lane / SHARE) * 2654435761u + 12345u;
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+        // a ray per lane: origin outside the unit cube the boxes live in, direction into it
+        const float ox = -1.5f - (float)(h & 255u) * (1.0f / 256.0f), oy = 0.3f + (float)((h >> 8) & 255u) * (0.4f / 256.0f), oz = 0.3f + (float)((h >> 16) & 255u) * (0.4f / 256.0f);
+        const float dx = 1.0f, dy = ((float)((h >> 4) & 255u) - 127.5f) * (0.2f / 256.0f), dz = ((float)((h >> 12) & 255u) - 127.5f) * (0.2f / 256.0f);
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        uint32_t ref = h % TOTAL_RECS;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(recs), 0, (int)0x7FFFFFFF, 0x00027000);
+        float best = 1e30f;
+        int sp = 0;
+        for (int it = 0; it < hops; ++it) {
+            float4 lmin = load16<KIND>(recs, rsrc, ref * 4u);
+            if (KIND >= 2) lmin.w = __uint_as_float((__float_as_uint(lmin.x) * 2654435761u + (uint32_t)it) % TOTAL_RECS);      // narrow loads do not reach the reference: keep the chain going
+            const float4 lmax = LOADS > 1 ? load16<KIND>(recs, rsrc, ref * 4u + 1u) : make_float4(lmin.x + 0.3f, lmin.y + 0.3f, lmin.z + 0.3f, 0.f);
+            float4 rmin = LOADS > 2 ? load16<KIND>(recs, rsrc, ref * 4u + 2u) : make_float4(lmin.y, lmin.z, lmin.x, lmax.w);
+            const float4 rmax = LOADS > 2 ? load16<KIND>(recs, rsrc, ref * 4u + 3u) : make_float4(lmax.y, lmax.z, lmax.x, 0.f);
+            if (KIND >= 2) rmin.w = __uint_as_float((__float_as_uint(rmin.x) * 2246822519u + (uint32_t)it) % TOTAL_RECS);
+            float d1 = slab(ox, oy, oz, ix, iy, iz, lmin, lmax, best);
+            float d2 = slab(ox, oy, oz, ix, iy, iz, rmin, rmax, best);
+            uint32_t nearRef = __float_as_uint(lmin.w), farRef = LOADS > 2 ? __float_as_uint(rmin.w) : (__float_as_uint(lmin.w) * 2654435761u) % TOTAL_RECS;
+            if (d1 > d2) { float t = d1; d1 = d2; d2 = t; uint32_t u = nearRef; nearRef = farRef; farRef = u; }
+            if (d2 != 1e30f) { s_stack[(sp & 15) * 64 + lane] = farRef; sp++; }         // push the far child
+            else if (d1 == 1e30f && sp > 0) { --sp; acc += s_stack[(sp & 15) * 64 + lane] & 1u; }   // a pop's LDS read (the chain itself goes on with nearRef)
+            ref = nearRef < TOTAL_RECS ? nearRef : TOTAL_RECS - 1u;      // never leave the table, whatever a diagnostic variant made of the reference
+            acc += (uint32_t)(d1 != 1e30f);
+        }
+        acc += ref;
+    }
+    out[wave * 64 + lane] = acc;
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) { stamps[wave * 3 + 0] = r0; stamps[wave * 3 + 1] = r1; stamps[wave * 3 + 2] = c1 - c0; }
+}
+
+struct Result { double ms, clockGhz, recPerCyclePerCu, cyclesPerHop; };
+
+template <int LOADS, int SHARE, int KIND = 0>
+static Result run(const float4* dRecs, int waves, int hops, uint32_t activeLanes, uint32_t* dOut, unsigned long long* dStamps, int numCus)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    chain_kernel<LOADS, SHARE, KIND><<<waves, 64>>>(dRecs, 16, activeLanes, dOut, dStamps);      // warm the caches / clocks
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    chain_kernel<LOADS, SHARE, KIND><<<waves, 64>>>(dRecs, hops, activeLanes, dOut, dStamps);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> st((size_t)waves * 3);
+    hipMemcpy(st.data(), dStamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    // in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS item 6), median over waves;
+    // launch extent = last end - first start on the 100 MHz real-time counter
+    std::vector<double> clk; unsigned long long first = ~0ull, last = 0; double cycSum = 0;
+    for (int w = 0; w < waves; ++w) {
+        const unsigned long long a = st[(size_t)w * 3], b = st[(size_t)w * 3 + 1], c = st[(size_t)w * 3 + 2];
+        if (b > a) clk.push_back((double)c / (double)(b - a) * 0.1);
+        first = std::min(first, a); last = std::max(last, b); cycSum += (double)c;
+    }
+    std::sort(clk.begin(), clk.end());
+    Result r;
+    r.clockGhz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+    const double extentS = (double)(last - first) * 1e-8;                     // 100 MHz ticks
+    r.ms = extentS * 1e3;
+    (void)ms;
+    const double recs = (double)waves * activeLanes * hops;      // lane-level record fetches (SHARE > 1: several lanes fetch the same record)
+    r.recPerCyclePerCu = recs / (extentS * r.clockGhz * 1e9 * numCus);
+    r.cyclesPerHop = cycSum / waves / hops;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return r;
+}
+
+int main(int argc, char** argv)
+{
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+    const int numCus = prop.multiProcessorCount;
+    float4* dRecs; hipMalloc(&dRecs, (size_t)TOTAL_RECS * 64);
+    uint32_t* dOut; unsigned long long* dStamps;
+    const int maxWaves = numCus * 32;
+    hipMalloc(&dOut, (size_t)maxWaves * 64 * 4); hipMalloc(&dStamps, (size_t)maxWaves * 3 * 8);
+    struct Mix { const char* name; float hot, warm; };
+    const Mix mixes[] = { { "kernel mix (multi-1M: 89 % L1 line hits, 72 % L2 hits)", 0.56f, 0.317f },
+                          { "all records L1-resident", 1.0f, 0.0f },
+                          { "all records from L2", 0.0f, 1.0f },
+                          { "all records from the Infinity Cache", 0.0f, 0.0f } };
+    std::vector<float> host((size_t)TOTAL_RECS * 16);
+    FILE* js = argc > 1 ? fopen(argv[1], "w") : nullptr;
+    if (js) fprintf(js, "{\"device\": \"%s\", \"cus\": %d, \"runs\": [\n", prop.gcnArchName, numCus);
+    bool firstJs = true;
+    printf("%s, %d CUs; every wave 64-thread workgroup with 5 KiB LDS, launch_bounds(64, 8); hops per lane 512\n", prop.gcnArchName, numCus);
+    for (const Mix& m : mixes) {
+        Rng rng{ 0x9E3779B97F4A7C15ull };
+        for (uint32_t i = 0; i < TOTAL_RECS; ++i) {
+            float* r = &host[(size_t)i * 16];
+            for (int b = 0; b < 2; ++b) {
+                // boxes inside the unit cube, wide enough that about half the slab tests pass
+                const float cx = rng.unit(), cy = 0.2f + 0.6f * rng.unit(), cz = 0.2f + 0.6f * rng.unit(), e = 0.15f + 0.35f * rng.unit();
+                r[b * 8 + 0] = cx - e; r[b * 8 + 1] = cy - e; r[b * 8 + 2] = cz - e;
+                r[b * 8 + 4] = cx + e; r[b * 8 + 5] = cy + e; r[b * 8 + 6] = cz + e; r[b * 8 + 7] = 0.0f;
+                const uint32_t ref = pick(rng, m.hot, m.warm);
+                memcpy(&r[b * 8 + 3], &ref, 4);
+            }
+        }
+        hipMemcpy(dRecs, host.data(), host.size() * 4, hipMemcpyHostToDevice);
+        printf("\n== %s (hot %.3f / warm %.3f / cold %.3f)\n", m.name, m.hot, m.warm, 1.0f - m.hot - m.warm);
+        printf("%-26s %6s %6s %9s %10s %16s %12s\n", "variant", "w/SIMD", "lanes", "ms", "clock GHz", "records/cyc/CU", "cycles/hop");
+        auto report = [&](const char* variant, int wps, uint32_t lanes, const Result& r) {
+            printf("%-26s %6d %6u %9.3f %10.3f %16.4f %12.0f\n", variant, wps, lanes, r.ms, r.clockGhz, r.recPerCyclePerCu, r.cyclesPerHop);
+            if (js) {
+                fprintf(js, "%s{\"mix\": \"%s\", \"hot\": %.3f, \"warm\": %.3f, \"variant\": \"%s\", \"waves_per_simd\": %d, \"active_lanes\": %u, \"ms\": %.4f, \"clock_ghz\": %.4f, "
+                            "\"records_per_cycle_per_cu\": %.5f, \"cycles_per_hop\": %.1f}", firstJs ? "" : ",\n", m.name, m.hot, m.warm, variant, wps, lanes, r.ms, r.clockGhz,
+                        r.recPerCyclePerCu, r.cyclesPerHop);
+                firstJs = false;
+            }
+        };
+        for (int wps : { 8, 4, 2, 1 })
+            for (uint32_t lanes : { 64u, 28u }) report("4 x dwordx4 (the kernel's)", wps, lanes, run<4, 1>(dRecs, numCus * 4 * wps, 512, lanes, dOut, dStamps, numCus));
+        // diagnostics at full occupancy: fewer loads per record, shared chains
+        report("2 x dwordx4", 8, 64, run<2, 1>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("1 x dwordx4", 8, 64, run<1, 1>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("4 x dwordx4, 4 lanes/chain", 8, 64, run<4, 4>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("4 x dwordx4, 16 lanes/chain", 8, 64, run<4, 16>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("4 x buffer_load_dwordx4", 8, 64, run<4, 1, 1>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("4 x buffer_load_dwordx4", 8, 28, run<4, 1, 1>(dRecs, numCus * 32, 512, 28, dOut, dStamps, numCus));
+        report("4 x dwordx2", 8, 64, run<4, 1, 2>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("4 x dword", 8, 64, run<4, 1, 3>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("4 x dword, 16 lanes/chain", 8, 64, run<4, 16, 3>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+        report("4 x dwordx4, 16 l/c, 28 lanes", 8, 28, run<4, 16>(dRecs, numCus * 32, 512, 28, dOut, dStamps, numCus));
+    }
+    if (js) { fprintf(js, "\n]}\n"); fclose(js); }
+    return 0;
+}
