@@ -23,19 +23,19 @@ of the N > 1 lines. Rays = primary rays + secondary rays actually traced, counte
 launch outside the timed region (and checked against the oracle in tests/).
 
 The JSON line also carries
-  roofline     : the dominant kernel (crt_trace_kernel) against the HBM roofline the way it can be true:
-                 `achieved` = HBM-side bytes per launch MEASURED by the committed PMC passes of this same command
-                 (profiles/*_summary.json: FETCH_SIZE + WRITE_SIZE, per launch) / the kernel's device time per launch
-                 from HIP events, `peak` = 8 TB/s, `frac` = achieved / peak (<= 1 by construction; null when no PMC
-                 profile of this workload is committed). SURVEY.md 8d's layout-independent ALGORITHMIC bytes (64 B x
-                 inner visits + 48 B x triangle tests + 80 B x instance records + fixed per-hit / per-miss / per-pixel
-                 bytes) are reported next to it as `algorithmic_*`: they exceed what reaches HBM many times over (the
-                 hot data sits in L1/L2/Infinity Cache), so their rate is not a fraction of any roofline.
-                 `gather`: real (post-cull) 64-B child-pair fetches per cycle per CU against the vector-memory pipeline's
-                 ceiling for such fetches (tools/ubench/gather.hip), with the fully-divergent-from-L2 rate as a reference
-                 point; `valu`: VALU issue occupancy (2 cycles per wave64 instruction on a SIMD-32), lane utilisation and L1
-                 line accesses per cycle from the committed PMC passes: no unit is saturated -- the kernel waits on
-                 dependent gathers.
+  roofline     : the dominant kernel (crt_trace_kernel) against the ceiling that binds it -- the CU's vector-memory path
+                 serving DEPENDENT 64-B record gathers: `achieved` = real (post-cull) child-pair fetches per cycle per CU
+                 at the shader clock MEASURED beside the frames in flight (crt_debug_measure_clock), `peak` = the same
+                 figure for the chain microbenchmark at full chain occupancy and the kernel's cache-hit mix
+                 (tools/ubench/chain.hip, profiles/r*_ubench_chain.json), `frac` = achieved / peak; the same triple again as
+                 `chain`, with the ceiling at the kernel's own lane utilisation next to it. The contract's HBM roofline
+                 stays beside it: `hbm` = {achieved = PMC-measured FETCH_SIZE + WRITE_SIZE bytes per launch / device time
+                 per launch, peak = 8 TB/s, frac} (`hbm_frac`; null when no PMC profile of this workload is committed) and
+                 `traffic`. SURVEY.md 8d's layout-independent ALGORITHMIC bytes are reported as `algorithmic_*`: they
+                 exceed what reaches HBM many times over (L1/L2/Infinity Cache, the instance cull), so their rate is not
+                 a fraction of any roofline. `valu`: issue occupancy / lane utilisation / L1 accesses from the PMC passes.
+  with_shadow_rays / dense_view / reference_assets : BASELINE configs 3-4 as written (primary + 1 shadow ray), the dense view
+                 of the same scene, and upstream's own Sponza + Sibenik assets -- each outside the contract's timed region.
   cpu_baseline : the reference's CPU path timed on this box's host cores (rank 0, N == 1 only): the mirrored
                  CPU_RayCast (CPURayTrace.cpp:186-249, SSE flavour with upstream's rcpps/dpps instruction mix) over the
                  primary rays of the bench frame at 1 thread and at all usable cores, and the scalar Trace oracle
@@ -69,6 +69,24 @@ def algorithmic_bytes(c, pixels):
 #    reference point, not a bound -- coherent packets (many lanes on one line, L1 hits) legitimately run above it.
 GATHER_CEILING_UNIFORM = 64.0 / 17.0
 GATHER_DIVERGENT_L2 = 64.0 / 181.0
+
+
+def chain_ceiling():
+    """The dependent-gather ceiling from the committed run of tools/ubench/chain.hip (newest round first): records per cycle
+    per CU at 8 waves/SIMD and the trace kernel's cache-hit mix, with 64 and with 28 chasing lanes per wave."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench_chain.json")), reverse=True):
+        try:
+            runs = json.load(open(path))["runs"]
+            pick = lambda lanes: [r for r in runs if r["mix"].startswith("kernel mix") and r.get("variant", "4 x dwordx4").startswith("4 x dwordx4 (")
+                                  and r["waves_per_simd"] == 8 and r["active_lanes"] == lanes]
+            full, part = pick(64), pick(28)
+            if full:
+                return {"full": full[0]["records_per_cycle_per_cu"], "lanes28": part[0]["records_per_cycle_per_cu"] if part else None,
+                        "clock_ghz": full[0]["clock_ghz"], "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
 def usable_cpus():
@@ -175,8 +193,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the 3840x2160 one-GPU point of the N = 1 line (profiling runs: it launches the same kernel at another size)")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (+ synchronous frames): no config-5 point, no sub-records (A/B runs)")
+    ap.add_argument("--diag-mix3", action="store_true", help="profiling aid: every step is ONE dispatch tracing the frame three times with interleaved tile lists "
+                                                             "(CRT_RENDER_DIAG_MIX3: the wave mix of three frames in flight, visible to a PMC pass); synchronous; rates are per 3 frames")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    if args.diag_mix3:
+        args.frames_in_flight, args.no_extras, args.no_cpu_baseline = 1, True, True
     if args.no_extras:
         args.no_config5 = True
 
@@ -263,9 +285,14 @@ def main():
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible (CRT_BENCH_REHEARSE=1 lists GPU 0 {n} times: functional rehearsal)")
     width = args.width or (1920 if n == 1 else 3840)
     height = args.height or (1080 if n == 1 else 2160)
-    # scene files are generated once (rank 0) into the shared cache directory
+    # scene files are generated once (rank 0) into the shared cache directory; with several ranks rank 0 also imports the
+    # meshes once on the host so that their .clm caches exist (AssetManager.cpp:363-381: ImportMesh prefers <stem>.clm) --
+    # N ranks then read N caches instead of running N OBJ parses at once, and build their BVHs on their GPUs (crt_build_bvh)
     if rank == 0:
         sc = scenes.get(args.scene)
+        if n > 1:
+            with driver.Session(64, 64, host_only=True) as pre:
+                pre.load_scene(sc)
     if dist is not None:
         dist.barrier(group=ctl)
     if rank != 0:
@@ -290,10 +317,14 @@ def main():
             single = (time.perf_counter() - t0) / 10
     t_load = time.time()
     s = driver.Session(width, height, device=device_index, devices=inproc_devices)
-    s.load_scene(sc)
+    s.load_scene(sc, device_bvh_build=(n > 1))
     if not inproc:
         s.set_row_bands(args.band_rows, rank, n)
     t_load = time.time() - t_load
+    if dist is not None:                       # the slowest rank's load is the job's
+        tl = torch.tensor([t_load], dtype=torch.float64, device=red_device)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX, group=ctl)
+        t_load = float(tl.item())
 
     # instrumented launch (untimed): rays and work counters of this rank's share of the frame
     s.render_raw(8 | (32 if args.shadows else 0))
@@ -315,7 +346,7 @@ def main():
     p_args, p_iv, p_ip = C.byref(targs), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp)
     hip = _lib.hip()
     crt_render = hip.crt_render
-    flags = (4 if flight > 1 else 0) | (32 if args.shadows else 0)   # CRT_RENDER_ASYNC, CRT_RENDER_SHADOWS
+    flags = (4 if flight > 1 else 0) | (32 if args.shadows else 0) | (1024 if args.diag_mix3 else 0)   # CRT_RENDER_ASYNC, CRT_RENDER_SHADOWS, CRT_RENDER_DIAG_MIX3
     stats = _lib.CrtFrameStats()
 
     # N > 1: the same workload on ONE GPU (this rank renders the whole frame, untimed by the contract clock), so the
@@ -350,6 +381,35 @@ def main():
     _lib.check(hip.crt_frame_time_stats(C.byref(stats), 0), "crt_frame_time_stats")
     launch_ms = stats.sumMs[2] / max(1, stats.frames)
     extent_ms = stats.extentMs / max(1, stats.frames)
+    # steady state: the first frame's latency is the pipeline's fill time; what follows it is K - 1 frames at the steady cadence.
+    # A 20-step run and a 200-step run agree on this figure; the contract's `value` includes the fill.
+    steady_ms = (stats.extentMs - stats.firstFrameMs) / max(1, stats.frames - 1) if stats.frames > 1 else extent_ms
+
+    def measure_view(sess, vflags, frames, label):
+        """An extra view / flag set outside the contract's timed region: counted launch for the rays, then `frames` frames."""
+        sess.render_raw(8 | (vflags & 32))
+        c = sess.counters()
+        a2, iv2, ip2 = sess.trace_args()
+        q = (C.byref(a2), iv2.ctypes.data_as(fp), ip2.ctypes.data_as(fp))
+        for _ in range(5):
+            _lib.check(crt_render(*q, vflags), "crt_render")
+        _lib.check(hip.crt_sync(), "crt_sync")
+        _lib.check(hip.crt_frame_time_stats(None, 1), "crt_frame_time_stats")
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            r = crt_render(*q, vflags)
+        _lib.check(hip.crt_sync(), "crt_sync")
+        dt = (time.perf_counter() - t0) / frames
+        _lib.check(r, "crt_render")
+        st = _lib.CrtFrameStats()
+        _lib.check(hip.crt_frame_time_stats(C.byref(st), 0), "crt_frame_time_stats")
+        steady = (st.extentMs - st.firstFrameMs) / max(1, st.frames - 1) if st.frames > 1 else dt * 1e3
+        return {"value": round(c["rays"] / dt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt * 1e3, 4), "frames": frames,
+                "rays_per_frame": c["rays"], "shadow_rays_per_frame": c["shadowRays"],
+                "primary_hit_fraction": round(c["secondary"] / max(1, c["primary"]), 4),
+                "inner_visits_per_ray": round(c["innerVisits"] / max(1, c["rays"]), 2), "tri_tests_per_ray": round(c["triTests"] / max(1, c["rays"]), 2),
+                "steady_state": {"value": round(c["rays"] / (steady * 1e-3) / 1e6, 2), "ms_per_step": round(steady, 4)},
+                "workload": label}
 
     # the same K frames the reference's way -- one at a time, Render() + clFinish (Renderer.cpp:305-367) -- reported
     # next to the headline as `synchronous_frames` (not part of the contract's timed region above)
@@ -365,6 +425,19 @@ def main():
         barrier()
         sync_elapsed = time.perf_counter() - t0
         _lib.check(rc, "crt_render")
+
+    # the shader clock the device holds while such frames are in flight: one probe wave per XCD watches s_memtime against the
+    # 100 MHz s_memrealtime for 300 us on its own stream while 24 frames run (cycle-based figures below use this, not 2.4 GHz)
+    clock_meas = None
+    if rank == 0:
+        for _ in range(24):
+            crt_render(p_args, p_iv, p_ip, flags)
+        ghz = C.c_double(0.0)
+        if hip.crt_debug_measure_clock(300, C.byref(ghz)) == 0 and ghz.value > 0.5:
+            clock_meas = float(ghz.value)
+        _lib.check(hip.crt_sync(), "crt_sync")
+    if dist is not None:
+        dist.barrier(group=ctl)
 
     # N > 1: the same K frames with every rank's bands DELIVERED per frame -- copied to pinned host memory behind the
     # frame's kernels (CRT_RENDER_READBACK moves only the rows a rank owns), the last copy complete before the clock
@@ -410,14 +483,32 @@ def main():
         my_bytes = algorithmic_bytes(cnt, own_rows * width)
         dev_s = extent_ms * 1e-3
         traffic, traffic_src = pmc_traffic("crt_trace_kernel", sc.name, width, height) if (n == 1 and not args.shadows) else (None, None)
-        achieved = None if traffic is None else traffic / dev_s / 1e9
-        frac = None if achieved is None else achieved / HBM_PEAK_GBS
-        assert frac is None or frac <= 1.0, f"measured HBM traffic rate {achieved} GB/s exceeds the peak: profile does not belong to this run"
-        assert pair_fetches / (n if inproc else 1) / (dev_s * 2.4e9 * 256) <= GATHER_CEILING_UNIFORM
-        clock_ghz = float(os.environ.get("CRT_SCLK_GHZ", "2.4"))             # MI355X peak engine clock (MI355X_MICROARCH.md)
+        hbm_achieved = None if traffic is None else traffic / dev_s / 1e9
+        hbm_frac = None if hbm_achieved is None else hbm_achieved / HBM_PEAK_GBS
         num_cus = int(hip.crt_device_name().decode().split(",")[-1].split()[0])
+        # shader clock: measured beside frames in flight; CRT_SCLK_GHZ overrides; the 2.4 GHz nominal clock only as a last resort
+        clock_ghz = float(os.environ["CRT_SCLK_GHZ"]) if "CRT_SCLK_GHZ" in os.environ else (clock_meas or 2.4)
+        clock_src = "CRT_SCLK_GHZ" if "CRT_SCLK_GHZ" in os.environ else ("crt_debug_measure_clock: s_memtime / s_memrealtime beside 24 frames in flight" if clock_meas else "nominal (probe failed)")
         ndev_here = n if inproc else 1                                          # in-process: counters are summed over the devices
         gather_rate = pair_fetches / ndev_here / (dev_s * clock_ghz * 1e9 * num_cus)   # 64-B records per cycle per CU
+        warnings = []
+        if hbm_frac is not None and hbm_frac > 1.0:
+            warnings.append(f"measured HBM traffic rate {hbm_achieved:.0f} GB/s exceeds the peak: the committed profile does not belong to this build")
+        ceil = chain_ceiling()
+        chain = None
+        if ceil:
+            chain = {"achieved": round(gather_rate, 4), "ceiling": round(ceil["full"], 4), "frac": round(gather_rate / ceil["full"], 4),
+                     "unit": "64-B records per cycle per CU",
+                     "ceiling_at_28_of_64_lanes": None if ceil["lanes28"] is None else round(ceil["lanes28"], 4),
+                     "frac_of_ceiling_at_28_lanes": None if ceil["lanes28"] is None else round(gather_rate / ceil["lanes28"], 4),
+                     "ceiling_source": ceil["source"], "clock_ghz": round(clock_ghz, 4), "clock_source": clock_src, "cus": num_cus,
+                     "note": "ceiling = tools/ubench/chain.hip: every lane of 8 waves/SIMD chasing its own chain of 64-B records (4 x dwordx4 + the inner step's "
+                             "arithmetic + LDS push per hop) at the trace kernel's measured hit mix (56 % of records L1-resident, 32 % from L2, 12 % from the "
+                             "Infinity Cache); the same rate from 2 to 8 waves/SIMD, i.e. a throughput limit of the CU's vector-memory path, not latency. The "
+                             "trace kernel runs with ~28 of 64 lanes working per vector instruction (ceiling_at_28_of_64_lanes) and its packets are partly "
+                             "coherent (several lanes per record), which is how it can sit above that second figure"}
+            if chain["frac"] > 1.0:
+                warnings.append("gather rate above the chain microbenchmark's ceiling: coherent packets fetch several lanes per record; see chain.note")
         out = {
             "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -431,17 +522,29 @@ def main():
                        "tiling": (f"16-row bands round-robin over {n} devices driven by ONE process (crt_init_devices {inproc_devices}), replicated scene, "
                                   "every frame gathered into device 0 by peer copies inside the timed region") if inproc
                                  else f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
-                       "frames_in_flight": flight, "control_plane": control_plane,
-                       "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2)},
+                       "frames_in_flight": flight, "control_plane": control_plane, "diag_mix3": bool(args.diag_mix3),
+                       "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2),
+                       "scene_load": ("max over ranks; meshes from the .clm caches rank 0 wrote once, BVH built on each GPU (crt_build_bvh)" if n > 1
+                                      else "OBJ import (or .clm cache) + host SAH build + uploads")},
+            "steady_state": {"value": round(rays_per_frame / (steady_ms * 1e-3) / 1e6, 2) if (n == 1 or inproc) else None,
+                             "unit": "Mrays/s", "ms_per_step": round(steady_ms, 4), "first_frame_ms": round(stats.firstFrameMs, 4),
+                             "note": "(device extent of the timed region - the first frame's latency) / (K - 1): the rate behind the pipeline's fill, which `value` "
+                                     "includes -- a 20-step and a 200-step run agree on this figure (rank 0's device)"},
             "inner_visits_per_s": round(tot["innerVisits"] * args.steps / elapsed_max, 0),
             "tri_tests_per_s": round(tot["triTests"] * args.steps / elapsed_max, 0),
             "kernel_ms": {"crt_trace_kernel_launch_mean": round(launch_ms, 4), "device_time_per_frame": round(extent_ms, 4),
                           "frame_latency_mean": round(stats.sumMs[0] / max(1, stats.frames), 4),
                           "device_time_per_frame_max_over_ranks": round(kernel_ms_max, 4)},
-            "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if frac is None else round(frac, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "achieved_definition": "PMC-measured FETCH_SIZE + WRITE_SIZE bytes per launch / device time per launch",
-                         "kernel": "crt_trace_kernel<COUNT=false, STAMP=false, SHADOW=%s, TLAS=false>" % ("true" if args.shadows else "false"),
+            "roofline": {"bound": "dependent 64-B gathers through the CU's vector-memory path (not HBM: see hbm_frac)",
+                         "achieved": None if chain is None else chain["achieved"], "peak": None if chain is None else chain["ceiling"],
+                         "unit": "64-B records per cycle per CU", "frac": None if chain is None else chain["frac"],
+                         "chain": chain,
+                         "hbm": {"achieved": None if hbm_achieved is None else round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": None if hbm_frac is None else round(hbm_frac, 4),
+                                 "achieved_definition": "PMC-measured FETCH_SIZE + WRITE_SIZE bytes per launch / device time per launch"},
+                         "hbm_frac": None if hbm_frac is None else round(hbm_frac, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "crt_trace_kernel<COUNT=false, STAMP=false, SHADOW=%s, TLAS=false, REFRACT=false>" % ("true" if args.shadows else "false"),
                          "launch_duration_ms": round(launch_ms, 4), "launches_in_flight": flight, "device_time_per_launch_ms": round(extent_ms, 4),
                          "algorithmic_bytes_per_launch": int(my_bytes),
                          "algorithmic_rate_gbs": round(my_bytes / dev_s / 1e9, 2),
@@ -451,15 +554,18 @@ def main():
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
                          "inner_visits_per_ray": round(cnt["innerVisits"] / max(1, cnt["rays"]), 2),
                          "tri_tests_per_ray": round(cnt["triTests"] / max(1, cnt["rays"]), 2),
-                         "gather": {"bound": "64-B child-pair records fetched per cycle per CU; ceiling = every lane of a wave on one L1-resident record (tools/ubench/gather.hip)",
-                                    "pair_fetches_per_launch": int(pair_fetches), "culled_root_visits_per_launch": int(culled.value),
-                                    "achieved": round(gather_rate, 4), "ceiling": round(GATHER_CEILING_UNIFORM, 4),
-                                    "frac": round(gather_rate / GATHER_CEILING_UNIFORM, 4),
-                                    "divergent_l2_reference": round(GATHER_DIVERGENT_L2, 4),
-                                    "ratio_to_divergent_l2": round(gather_rate / GATHER_DIVERGENT_L2, 4),
-                                    "clock_ghz": clock_ghz, "cus": num_cus},
+                         "gather": {"pair_fetches_per_launch": int(pair_fetches), "culled_root_visits_per_launch": int(culled.value),
+                                    "records_per_cycle_per_cu": round(gather_rate, 4),
+                                    "uniform_l1_reference": round(GATHER_CEILING_UNIFORM, 4), "divergent_l2_reference": round(GATHER_DIVERGENT_L2, 4),
+                                    "note": "reference points from tools/ubench/gather.hip (independent fetches): every lane on one L1-resident record / every lane on a different L2-resident record"},
                          "valu": pmc_valu("crt_trace_kernel", sc.name, width, height, dev_s, clock_ghz, num_cus) if (n == 1 and not args.shadows) else None},
         }
+        if warnings:
+            out["warnings"] = warnings
+        if n > 1:
+            out["config"]["gather_path"] = hip.crt_gather_path().decode() if inproc else "none: every rank keeps its bands (delivered_to_host* copy them to pinned host memory)"
+            if inproc:
+                out["config"]["peer_access"] = [int(hip.crt_peer_access(d)) for d in range(n)]
         if sync_elapsed is not None:
             out["synchronous_frames"] = {"value": round(rays_per_frame * args.steps / sync_elapsed / 1e6, 2), "unit": "Mrays/s",
                                          "ms_per_step": round(sync_elapsed * 1e3 / args.steps, 4),
@@ -474,6 +580,19 @@ def main():
         if single is not None:
             out["single_gpu_same_workload"] = {"value": round(rays_per_frame / single / 1e6, 2), "unit": "Mrays/s",
                                                "ms_per_step": round(single * 1e3, 4), "note": "rank 0 alone rendering the whole frame, 10 frames, same mode"}
+        extras = n == 1 and not args.no_extras and not args.width and not args.height and args.scene == "multi-1M" and not args.shadows
+        kx = max(20, min(100, args.steps))
+        if extras:
+            # BASELINE configs 3-4 as written ("primary + 1 shadow ray"): the shadow-ray extension on the bench scene (upstream has no
+            # shadow ray, kernel_main.cl:256-258; semantics defined by the oracle, bit-exact in tests/test_gpu_shadows.py)
+            out["with_shadow_rays"] = measure_view(s, flags | 32, kx, f"{sc.name} {width}x{height}, primary + reflection bounce + 1 any-hit shadow ray per lit first hit")
+            # ... on config 3's own scene too (sponza-class-250k is loaded below with the other scenes)
+            # the dense view of the same scene: 97 % of the primary rays hit, 46 inner visits per ray (the headline view is 69 % sky)
+            dense = scenes.get("multi-1M-dense")
+            s.set_camera(dense.camera_pos, dense.camera_front)
+            out["dense_view"] = measure_view(s, flags, kx, f"multi-1M-dense: the same scene seen from among its instances, {width}x{height}")
+            out["dense_view"]["synchronous_frames"] = measure_view(s, flags & ~4, kx, "same view, one frame at a time")["value"]
+            s.set_camera(sc.camera_pos, sc.camera_front)
         if n == 1 and not args.width and not args.height and not args.no_config5:
             # the N = 1 point of BASELINE config 5 (the 3840x2160 frame the N > 1 lines tile over the ranks), so that a scaling
             # curve has a base on the same workload; outside the contract's timed region
@@ -496,6 +615,26 @@ def main():
                                       "rays_per_frame": rays5, "frames": k5,
                                       "note": "the same scene at 3840x2160 on this one GPU (BASELINE config 5 at N = 1): the base of the N > 1 lines"}
             s.resize(width, height)
+        if extras:
+            # upstream's own assets (Sponza + Sibenik .clm caches with their 27 JPEG texture imports) and BASELINE config 3
+            # (sponza-class-250k, with its shadow ray): own sessions, one after the other (the library drives one at a time)
+            s.close()
+            for key, name, vflags in (("reference_assets", "sponza-sibenik", flags), ("config3_with_shadow_rays", "sponza-class-250k", flags | 32)):
+                sc2 = scenes.get(name)
+                t0 = time.time()
+                with driver.Session(width, height, device=device_index) as s2:
+                    s2.load_scene(sc2)
+                    load2 = time.time() - t0
+                    out[key] = measure_view(s2, vflags, kx, f"{name}: {sc2.num_tris} triangles, {len(sc2.instances)} instances, {width}x{height}"
+                                            + (", + 1 shadow ray per lit first hit" if vflags & 32 else ""))
+                    out[key]["synchronous_frames"] = measure_view(s2, vflags & ~4, kx, "same view, one frame at a time")["value"]
+                    out[key]["scene_load_s"] = round(load2, 2)
+                    tr2, src2 = pmc_traffic("crt_trace_kernel", name, width, height) if not (vflags & 32) else (None, None)
+                    if tr2:
+                        out[key]["hbm"] = {"traffic": tr2, "traffic_source": src2, "achieved_gbs": round(tr2 / (out[key]["steady_state"]["ms_per_step"] * 1e-3) / 1e9, 1),
+                                           "frac": round(tr2 / (out[key]["steady_state"]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            s = driver.Session(width, height, device=device_index)
+            s.load_scene(sc)
         if n == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
@@ -533,6 +672,26 @@ def main():
                 "trace_oracle": {"value": round(st["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
                                  "sample": f"scalar restatement of kernel_main.cl Trace, both bounces, one full frame ({st['rays']} rays, {dt:.2f} s)",
                                  "rays_match_gpu": bool(st["rays"] == cnt["rays"])}}
+            # (3) BASELINE config 1 as written: cornell-1k (984 triangles), 640x480, one primary ray per pixel through CPU_RayCast on the
+            # host -- the reference's own CPU path at the size its plumbing config names (a host-only session: no GPU involved)
+            s.close()
+            c1 = scenes.get("cornell-1k")
+            with driver.Session(640, 480, host_only=True) as hs:
+                hs.load_scene(c1)
+                iv1, ip1, pos1 = hs.camera()
+                o1 = oracle_lib.Oracle(hs.arenas(), nthreads=threads)
+                d1 = np.ascontiguousarray(o1.raygen(640, 480, iv1, ip1).reshape(-1, 3))
+                og1 = np.ascontiguousarray(np.tile(np.asarray(pos1, np.float32), (len(d1), 1)))
+                t0 = time.perf_counter(); r1 = hs.cpu_raycast(og1, d1, nthreads=1, sse=True); c1_dt1 = time.perf_counter() - t0
+                c1_dtn = None
+                for _ in range(30):
+                    t0 = time.perf_counter(); hs.cpu_raycast(og1, d1, nthreads=threads, sse=True); d = time.perf_counter() - t0
+                    c1_dtn = d if c1_dtn is None else min(c1_dtn, d)
+            out["cpu_baseline"]["config1_cornell_1k_640x480"] = {
+                "value": round(len(d1) / c1_dtn / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "one_thread": {"value": round(len(d1) / c1_dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1},
+                "primary_hits": int((r1["distance"] < 1e29).sum()),
+                "sample": f"CPU_RayCast (SSE flavour) over the {len(d1)} primary rays of cornell-1k at 640x480: {c1_dt1:.3f} s on one thread, best of 30 passes on {threads}: {c1_dtn:.4f} s"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     s.close()

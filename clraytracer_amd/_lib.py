@@ -24,7 +24,7 @@ class CrtTraceArgs(C.Structure):
 
 
 class CrtFrameStats(C.Structure):
-    _fields_ = [("frames", C.c_uint64), ("sumMs", C.c_double * 4), ("extentMs", C.c_double)]
+    _fields_ = [("frames", C.c_uint64), ("sumMs", C.c_double * 4), ("extentMs", C.c_double), ("firstFrameMs", C.c_double)]
 
 
 class CrtCounters(C.Structure):

@@ -54,6 +54,7 @@ struct FrameSlot {
     CrtMeshInstance* instances = nullptr; CrtDevInstance* devInstances = nullptr; float4* instBounds = nullptr;
     CrtTlasNode* tlas = nullptr; uint32_t* alwaysList = nullptr; uint32_t tlasNodes = 0, numAlways = 0;
     unsigned long long instVersion = 0;        // 0 = never filled (the master starts at 1)
+    uint32_t* mixOrder = nullptr; uint32_t* mixLen = nullptr; size_t mixCap = 0; int mixSlots = -1;   // CRT_RENDER_DIAG_MIX3 launch lists
     char* staging = nullptr; hipEvent_t staged = nullptr;   // pinned staging block and "its copies have been issued and done" event
     // in-process multi-GPU (crt_init_devices): a secondary device records `partDone` behind the copy of its bands into the
     // primary's frame; the primary records `slotDone` behind everything a frame queues on this slot (incl. a read-back)
@@ -104,7 +105,7 @@ struct State {
     bool sceneValid = true;
     double msSum[4] = { 0, 0, 0, 0 }; unsigned long long framesTimed = 0;   // crt_frame_time_stats
     float ms[4] = { 0, 0, 0, 0 }; unsigned long long msSeq = 0, frameSeq = 0;   // timing of the newest frame read back so far
-    hipEvent_t statStart = nullptr; bool statStartArmed = true, statStartValid = false; unsigned long long statStartSeq = 0; double statExtent = 0;
+    hipEvent_t statStart = nullptr; bool statStartArmed = true, statStartValid = false; unsigned long long statStartSeq = 0; double statExtent = 0, statFirstMs = 0;
     CrtCounters lastCounters; unsigned long long lastCulled = 0;
     // in-process multi-GPU: this device renders band `rank` of `nRanks`; `primary` (rank 0) owns the frame that is read
     State* primary = nullptr; State* group[CRT_MAX_DEVICES] = { nullptr }; int groupSize = 1;
@@ -434,6 +435,7 @@ int collect_set(EventSet& es)
         float ext = 0;
         HIPCHK(hipEventElapsedTime(&ext, g.statStart, frameEnd));
         if ((double)ext > g.statExtent) g.statExtent = (double)ext;
+        if (es.seq == g.statStartSeq) g.statFirstMs = (double)ext;      // the first frame of the extent: fill time of the pipeline
     }
     if (es.seq >= g.msSeq) { memcpy(g.ms, ms, sizeof ms); g.msSeq = es.seq; }
     if (es.flags & CRT_RENDER_COUNTERS) {
@@ -563,7 +565,7 @@ static void release_all()
                      g.texels, g.materials, g.textures, g.rays, g.counters, g.err,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount };
     for (FrameSlot& fs : g.slot) {
-        void* q[] = { fs.out, fs.aux, fs.ovf, fs.order, fs.len, fs.cost, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
+        void* q[] = { fs.out, fs.aux, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
         for (void* p : q) if (p) (void)hipFree(p);
         if (fs.staging) (void)hipHostFree(fs.staging);
         if (fs.staged) (void)hipEventDestroy(fs.staged);
@@ -1025,6 +1027,33 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // Feedback launch lists serve synchronous frames, whose end is decided by their slowest waves. With frames in flight the
     // tail is hidden by the next frame and the lists only cost (cost atomics, the sort launch, quadrant waves at a quarter
     // of the lane utilisation): 7.58 with, 7.72 Gray/s without on multi-1M -> pipelined frames use the plain row-interleaved order.
+    const bool mix3 = (flags & CRT_RENDER_DIAG_MIX3) != 0;
+    if (mix3) {
+        if (pipelined || variant || g.groupSize > 1 || (flags & (CRT_RENDER_STAMPS | CRT_RENDER_WRITE_RAYS | CRT_RENDER_FXAA))) return CRT_E_UNSUPPORTED;
+        // three copies of the plain row-interleaved order, copy j starting a third of the XCD's list later: entry 3 i + j = tile (i + j S / 3) mod S
+        const int S3 = 3 * F.slotsPerXcd;
+        if ((size_t)8 * S3 > fs.mixCap) {
+            HIPCHK(hipStreamSynchronize(fs.stream));
+            if (fs.mixOrder) (void)hipFree(fs.mixOrder);
+            if (fs.mixLen) (void)hipFree(fs.mixLen);
+            fs.mixOrder = nullptr; fs.mixLen = nullptr; fs.mixCap = 0; fs.mixSlots = -1;
+            HIPCHK(hipMalloc(&fs.mixOrder, sizeof(uint32_t) * 8 * (size_t)S3));
+            HIPCHK(hipMalloc(&fs.mixLen, sizeof(uint32_t) * 8));
+            fs.mixCap = (size_t)8 * S3;
+        }
+        if (fs.mixSlots != F.slotsPerXcd) {
+            std::vector<uint32_t> h((size_t)8 * S3), len(8, (uint32_t)S3);
+            for (int x = 0; x < 8; ++x)
+                for (int i = 0; i < F.slotsPerXcd; ++i)
+                    for (int j = 0; j < 3; ++j) h[(size_t)x * S3 + 3 * i + j] = (uint32_t)((i + j * (F.slotsPerXcd / 3)) % F.slotsPerXcd);
+            HIPCHK(hipMemcpyAsync(fs.mixOrder, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, fs.stream));
+            HIPCHK(hipMemcpyAsync(fs.mixLen, len.data(), 8 * sizeof(uint32_t), hipMemcpyHostToDevice, fs.stream));
+            HIPCHK(hipStreamSynchronize(fs.stream));      // the host vectors go out of scope
+            fs.mixSlots = F.slotsPerXcd;
+        }
+        F.order = fs.mixOrder; F.listLen = fs.mixLen; F.listCap = S3; F.cost = nullptr;
+        grid = 8u * (unsigned)S3;
+    } else
     if (g.feedback && !g.wavefront && (!pipelined || g.feedbackAsync)) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
     {   // overflow blocks: one per workgroup of the largest launch of this frame (wavefront: the bounce launch may be larger)
         size_t blocks = grid;
@@ -1037,7 +1066,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // A plain frame records only two (RayGen is fused, PostProcess off): [0] == [1], [2] == [3].
     if (g.statStartArmed) {                  // first frame since the statistics were reset: start of the extent
         HIPCHK(hipEventRecord(g.statStart, fs.stream));
-        g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0;
+        g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0; g.statFirstMs = 0;
     }
     es.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
     es.evPost = (flags & (CRT_RENDER_POSTPROCESS | CRT_RENDER_UNORM8 | CRT_RENDER_FXAA)) != 0;
@@ -1131,7 +1160,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     }
     g.cur = slot;
     es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
-    const bool sorted = F.order != nullptr;
+    const bool sorted = F.order != nullptr && !mix3;
     if (sorted) {
         // did the view change since the last sorted frame? (camera matrices and position, instance tables)
         float view[35];
@@ -1346,10 +1375,11 @@ int crt1_frame_time_stats(CrtFrameStats* out, int reset)
         out->frames = g.framesTimed;
         for (int k = 0; k < 4; ++k) out->sumMs[k] = g.msSum[k];
         out->extentMs = g.statExtent;
+        out->firstFrameMs = g.statFirstMs;
     }
     if (reset) {
         for (int k = 0; k < 4; ++k) g.msSum[k] = 0.0;
-        g.framesTimed = 0; g.statExtent = 0; g.statStartArmed = true; g.statStartValid = false;
+        g.framesTimed = 0; g.statExtent = 0; g.statFirstMs = 0; g.statStartArmed = true; g.statStartValid = false;
     }
     return CRT_OK;
 }

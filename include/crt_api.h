@@ -51,6 +51,10 @@ enum {
     CRT_RENDER_REFRACTION  = 256, /* extension (upstream README TODO "refraction / transculency", no upstream code): at the first hit
                                      of a material whose MTL `d` (opacity, Material::roughness) is below 1 the bounce ray is the
                                      refracted ray (index 1.5) with (1 - opacity) of the energy; defined by the oracle, see DESIGN.md */
+    CRT_RENDER_DIAG_MIX3   = 1024, /* diagnostic (profiling aid): ONE Trace dispatch that traces the frame three times, tile lists
+                                     interleaved a third of the frame apart -- the wave mix of three frames in flight in a dispatch a
+                                     PMC pass can see (rocprofv3 serialises dispatches, so real frames in flight cannot be profiled).
+                                     Same pixels (every copy stores the same value). One device, synchronous, default kernel only */
     CRT_RENDER_FXAA        = 512  /* extension: upstream's FXAA function (kernel_main.cl:289-340) is dead code -- its call is commented out
                                      (kernel_main.cl:349), it returns nothing and would read pixels PostProcess is rewriting. Run it
                                      as the first PostProcess stage (or alone, without CRT_RENDER_POSTPROCESS), reading the unmodified
@@ -177,6 +181,8 @@ typedef struct CrtFrameStats {
     uint64_t frames;
     double sumMs[4];      /* same four intervals as crt_last_kernel_ms */
     double extentMs;      /* start of the first frame -> end of the last one to finish */
+    double firstFrameMs;  /* start -> end of the first frame since the reset: the pipeline's fill time. (extentMs - firstFrameMs) /
+                             (frames - 1) is the steady-state device time per frame, independent of how many frames were timed */
 } CrtFrameStats;
 int crt_frame_time_stats(CrtFrameStats* out, int reset);
 int crt_get_counters(CrtCounters* out);

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false, false, false, false, false, true>"   # <COUNT, STAMP, SHADOW, TLAS, REFRACT, ALLSTEPS>: the kernel of the timed region
+    kern = sys.argv[2] if len(sys.argv) > 2 else "crt_trace_kernel<false, false, false, false, false>"   # <COUNT, STAMP, SHADOW, TLAS, REFRACT>: the kernel of the timed region
     base = os.path.join(ROOT, "gpurun_out")
     out = {"tag": tag, "kernel": kern, "kernel_stats": [], "counters": {}, "bench_line": None}
     def newest(pattern):
@@ -81,6 +81,16 @@ def main():
                         ("TCP_PENDING_STALL_CYCLES_sum", "tcp_pending_stall"), ("TA_ADDR_STALLED_BY_TC_CYCLES_sum", "ta_addr_stalled_by_tc")):
             if k in c:
                 d[name] = c[k] / (256.0 * kcyc)
+    if "SQ_INSTS_VMEM_RD" in c:
+        d["vmem_rd_insts_per_launch"] = c["SQ_INSTS_VMEM_RD"]
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+            d["l1_lines_per_vmem_rd_inst"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / max(1.0, c["SQ_INSTS_VMEM_RD"])
+        if "GRBM_GUI_ACTIVE" in c:
+            # tools/ubench/chain.hip: a vector load costs the CU's address pipeline ~12-16 cycles + ~0.5 cycle per distinct line
+            kcyc = c["GRBM_GUI_ACTIVE"] / 8.0
+            d["vmem_rd_insts_per_cu_per_kcycle"] = c["SQ_INSTS_VMEM_RD"] / 256.0 / kcyc * 1e3
+    if "SQ_INSTS_SMEM" in c:
+        d["smem_insts_per_launch"] = c["SQ_INSTS_SMEM"]
     if "SQ_WAVE_CYCLES" in c and "SQ_WAVES" in c:
         d["wave_quad_cycles_per_wave"] = c["SQ_WAVE_CYCLES"] / max(1.0, c["SQ_WAVES"])
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
@@ -93,7 +103,7 @@ def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_summary.json"), "w"), indent=1)
     with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
-        f.write(f"# rocprofv3 summary `{tag}` (MI355X, `python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-config5`)\n\n")
+        f.write(f"# rocprofv3 summary `{tag}` (MI355X, `python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-extras` + the PROF_ARGS of the run, see the bench line)\n\n")
         if out["bench_line"]:
             b = out["bench_line"]
             f.write(f"bench line under the profiler: {b['value']} {b['unit']}, {b['ms_per_step']} ms/frame, workload `{b['config']['workload']}`\n\n")
