@@ -373,11 +373,25 @@ struct Traversal {
         if (COUNT) { lc.traversals++; lc.pops++; }
     }
     // kernel_main.cl:142-157: fetch the child pair, two slab tests, near child first, far child pushed
-    template <class STK>
+    template <bool TRY_SCALAR, class STK>
     __device__ __forceinline__ void inner(const CrtDevScene& S, const STK& stack, Closest& c, LaneCounters& lc)
     {
-        const float4* p = S.pairs + (size_t)ref * 4;            // one aligned 64-byte record
-        const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+        float4 lmin, lmax, rmin, rmax;
+#if CRT_SCALAR_INNER
+        // every lane of this step on the same node (the top of a tree under a coherent packet): one scalar load instead of four
+        // vector loads, the boxes as scalar operands
+        const uint32_t ref0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
+        if (TRY_SCALAR && __ballot(ref != ref0) == 0) {
+            const crt_const_f32x4_ptr q = (crt_const_f32x4_ptr)(S.pairs + (size_t)ref0 * 4);
+            const crt_f32x4 a = q[0], b = q[1], c4 = q[2], e = q[3];
+            lmin = make_float4(a.x, a.y, a.z, a.w); lmax = make_float4(b.x, b.y, b.z, b.w);
+            rmin = make_float4(c4.x, c4.y, c4.z, c4.w); rmax = make_float4(e.x, e.y, e.z, e.w);
+        } else
+#endif
+        {
+            const float4* p = S.pairs + (size_t)ref * 4;        // one aligned 64-byte record
+            lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
+        }
         if (COUNT) lc.innerVisits++;
         float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
         float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
@@ -530,18 +544,30 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
 // for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
 // first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
 // ITERS (stamped diagnostic launches): the counters record wave-level trips instead of per-ray work.
+#ifndef CRT_SCALAR_INNER
+#define CRT_SCALAR_INNER 0     // 1: scalar fetch for wave-uniform nodes in both inner steps of a trip; 2: in the first only
+#endif
 template <bool COUNT, bool ITERS, bool ANYHIT, class STK>
 __device__ __forceinline__ void trip_steps(const CrtDevScene& S, const STK& stack, Traversal<COUNT>& T, Closest& c, LaneCounters& lc, bool done)
 {
     if (!done && T.at_inner()) {
         if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
-        T.inner(S, stack, c, lc);
+        T.template inner<(CRT_SCALAR_INNER >= 1)>(S, stack, c, lc);
     }
     if (!done && T.at_leaf()) {
-        if (ITERS) { if (first_active_lane()) lc.triTests++; }
+        if (ITERS) {
+            if (first_active_lane()) lc.triTests++;
+            // wave-level triangle iterations of this leaf step = the largest count among the lanes taking it (3 vector loads each)
+            uint32_t n = (T.ref >> 24) & 0x7Fu; if (n == 0) n = S.bigLeaf[T.ref & 0x00FFFFFFu];
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o2 = (uint32_t)__shfl_xor((int)n, off, 64); n = o2 > n ? o2 : n; }
+            if (first_active_lane()) lc.misses += n;
+        }
         T.template leaf<ANYHIT>(S, stack, c, lc);
     }
-    if (!done && T.at_inner()) T.inner(S, stack, c, lc);      // lanes that just popped an inner node go on at once
+    if (!done && T.at_inner()) {
+        if (ITERS) { if (first_active_lane()) lc.hits++; }
+        T.template inner<(CRT_SCALAR_INNER == 1)>(S, stack, c, lc);      // lanes that just popped an inner node go on at once
+    }
 }
 
 template <bool COUNT, bool ITERS = false, bool ANYHIT = false, bool TLAS = false, class STK = CrtStack>

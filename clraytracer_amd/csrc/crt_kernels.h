@@ -315,10 +315,11 @@ void crt_trace_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsig
     if (STAMP) {
         const unsigned long long t1c = __builtin_amdgcn_s_memtime(), t1rt = __builtin_amdgcn_s_memrealtime();
         const uint32_t wOuter = wave_sum(lc.pops), wEnter = wave_sum(lc.traversals), wDescent = wave_sum(lc.innerVisits),
-                       wLeaf = wave_sum(lc.triTests), laneVisits = wave_sum(lc.rays);
+                       wLeaf = wave_sum(lc.triTests), laneVisits = wave_sum(lc.rays), wInner2 = wave_sum(lc.hits), wLeafIters = wave_sum(lc.misses);
         if ((threadIdx.x & 63) == 0) {
             unsigned long long* st = counters + 16 + (size_t)blockIdx.x * 8;
-            st[4] = wOuter; st[5] = wEnter; st[6] = wDescent; st[7] = ((unsigned long long)wLeaf << 32) | laneVisits;
+            st[4] = wOuter | ((unsigned long long)wInner2 << 32); st[5] = wEnter | ((unsigned long long)wLeafIters << 32);
+            st[6] = wDescent; st[7] = ((unsigned long long)wLeaf << 32) | laneVisits;
             st[0] = t0rt; st[1] = t1rt; st[2] = t1c - t0c;
             st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
         }

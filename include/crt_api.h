@@ -191,8 +191,9 @@ int crt_get_counters(CrtCounters* out);
  * real child-pair fetches are innerVisits - this. (Measurement aid for bench.py's gather-rate figure.) */
 int crt_get_culled_visits(uint64_t* out);
 /* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 8 x uint64 {start, end (s_memrealtime, 100 MHz),
- * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer / enter-instance / descent loops,
- * leaf trips << 32 | lane-level node visits}. Pass dst = NULL to query the wave count. */
+ * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer loop | second-inner-step executions << 32,
+ * enter-instance steps | wave-level triangle iterations << 32, first-inner-step executions, leaf steps << 32 | lane-level node
+ * visits}. Pass dst = NULL to query the wave count. */
 int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves);
 /* Diagnostic: the shader clock (GHz) the device holds under whatever load it carries while the call runs: one wave per XCD
  * watches s_memtime against the 100 MHz s_memrealtime for `micros` microseconds on a stream of its own (bench.py calls it

@@ -22,6 +22,6 @@ pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass misc GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY
 pass sq2 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR
-pass sq3 SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT
+( pass sq3 SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INST_CYCLES_VMEM_RD ) || echo "(optional pass sq3 not collected)"
 if [ "$mode" = full ]; then PROF_ARGS="$PROF_ARGS" tools/ta_only.sh $tag || exit 1; fi
 echo done

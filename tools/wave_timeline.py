@@ -52,11 +52,18 @@ if os.environ.get("CRT_KERNEL", "tile") == "persistent":
         print("%-8s passes/trips %.3fM  lanes %.2fM  -> %.1f lanes per trip" % (nm, hi(st[:, col]) / 1e6, lo(st[:, col]) / 1e6, lo(st[:, col]) / max(1.0, hi(st[:, col]))))
     print("cycles per wave: mean %.0f max %.0f ; total wave-cycles %.2fG" % (cyc.mean(), cyc.max(), cyc.sum() / 1e9))
     sys.exit(0)
-outer, enter, desc = st[:, 4].astype(np.float64), st[:, 5].astype(np.float64), st[:, 6].astype(np.float64)
+lo32 = lambda a: (a & np.uint64(0xFFFFFFFF)).astype(np.float64)
+hi32 = lambda a: (a >> np.uint64(32)).astype(np.float64)
+outer, enter, desc = lo32(st[:, 4]), lo32(st[:, 5]), st[:, 6].astype(np.float64)
+inner2, leaf_iters = hi32(st[:, 4]), hi32(st[:, 5])
 leaf, lanev = (st[:, 7] >> np.uint64(32)).astype(np.float64), (st[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
 cyc = st[:, 2].astype(np.float64)
 print("wave-level loop trips (sum over waves): outer %.2fM enter %.2fM descent %.2fM leaf %.2fM ; lane-level node visits %.2fM -> lanes active per descent trip %.1f" % (
     outer.sum() / 1e6, enter.sum() / 1e6, desc.sum() / 1e6, leaf.sum() / 1e6, lanev.sum() / 1e6, lanev.sum() / max(1.0, desc.sum())))
+print("wave-level step executions: first inner step %.2fM, second inner step %.2fM, leaf steps %.2fM with %.2fM triangle iterations, instance entries %.2fM" % (
+    desc.sum() / 1e6, inner2.sum() / 1e6, leaf.sum() / 1e6, leaf_iters.sum() / 1e6, enter.sum() / 1e6))
+print("  -> vector loads if every step took the vector path: inner 4 x %.2fM = %.2fM, leaf 3 x %.2fM = %.2fM, entries 4 x %.2fM = %.2fM (uniform entries use one scalar load instead)" % (
+    (desc.sum() + inner2.sum()) / 1e6, 4 * (desc.sum() + inner2.sum()) / 1e6, leaf_iters.sum() / 1e6, 3 * leaf_iters.sum() / 1e6, enter.sum() / 1e6, 4 * enter.sum() / 1e6))
 print("cycles per descent trip: all waves %.0f ; slowest 1%% of waves %.0f" % (cyc.sum() / max(1.0, desc.sum()), cyc[dur >= np.percentile(dur, 99)].sum() / max(1.0, desc[dur >= np.percentile(dur, 99)].sum())))
 top = np.argsort(-dur)[:8]
 print("slowest waves: descent trips", desc[top].astype(int), "leaf trips", leaf[top].astype(int), "enter", enter[top].astype(int), "lane visits", lanev[top].astype(int))
