@@ -32,6 +32,9 @@
 #include "../../include/crt_types.h"
 
 #define CRT_LEAF_BIT 0x80000000u
+#ifndef CRT_SCALAR_INNER
+#define CRT_SCALAR_INNER 1     // 1: scalar fetch for wave-uniform nodes in both inner steps of a trip; 2: in the first only; 0: never
+#endif
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
 #ifndef CRT_WAVES_PER_SIMD
 #define CRT_WAVES_PER_SIMD 8   // 32 waves per CU: 64 VGPRs (the trace kernel fits them without scratch) and 5 KiB of LDS each = the CU's 160 KiB
@@ -207,11 +210,8 @@ __device__ __forceinline__ float intersect_aabb(v3 o, v3 inv, float4 bmin, float
 }
 
 // kernel_main.cl:84-106; hot = {v0, edge1, edge2}
-__device__ __forceinline__ int intersect_triangle(v3 o, v3 d, const float* __restrict__ hot, Triout& out, uint32_t i)
+__device__ __forceinline__ int intersect_triangle(v3 o, v3 d, v3 x, v3 edge1, v3 edge2, Triout& out, uint32_t i)
 {
-    const v3 x = mk3(hot[0], hot[1], hot[2]);
-    const v3 edge1 = mk3(hot[3], hot[4], hot[5]);
-    const v3 edge2 = mk3(hot[6], hot[7], hot[8]);
     const v3 h = cross3(d, edge2);
     const float a = dot3(edge1, h);
     const float f = 1.0f / a;
@@ -253,6 +253,7 @@ __device__ __forceinline__ v3 mat3mul(const float* __restrict__ m, v3 v)
 }
 
 struct Closest { float distance; int hitInstance; int anyHit; Triout hit; };
+
 
 // diagnostic (ITERS builds only): true in exactly one active lane, so summing over lanes counts wave-level loop trips
 __device__ __forceinline__ bool first_active_lane() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
@@ -379,7 +380,11 @@ struct Traversal {
         float4 lmin, lmax, rmin, rmax;
 #if CRT_SCALAR_INNER
         // every lane of this step on the same node (the top of a tree under a coherent packet): one scalar load instead of four
-        // vector loads, the boxes as scalar operands
+        // vector loads, the boxes as scalar operands. (Round 2 measured the same idea as a wash -- the uniformity test costs every
+        // step -- but with the instance bounds and records on the scalar path the node fetches are 3/4 of the vector-memory
+        // instructions that bound the kernel: sponza-sibenik +6 %, multi-1M-dense +2 %, multi-1M and nanosuit-demo +-0, synchronous
+        // frames +0...5 %. The same for leaves -- a uniform triangle through scalar loads -- lost 18 %: the 9 scalar operands push the
+        // kernel into scratch, and small triangles are never shared by a whole packet.)
         const uint32_t ref0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
         if (TRY_SCALAR && __ballot(ref != ref0) == 0) {
             const crt_const_f32x4_ptr q = (crt_const_f32x4_ptr)(S.pairs + (size_t)ref0 * 4);
@@ -430,7 +435,8 @@ struct Traversal {
         if (n == 0) n = S.bigLeaf[first];
         for (uint32_t i = first, end = first + n; i < end; ++i) {
             if (COUNT) lc.triTests++;
-            inters |= intersect_triangle(mo, md, S.triHot + (size_t)i * 9, tr, i);
+            const float* __restrict__ hot = S.triHot + (size_t)i * 9;
+            inters |= intersect_triangle(mo, md, mk3(hot[0], hot[1], hot[2]), mk3(hot[3], hot[4], hot[5]), mk3(hot[6], hot[7], hot[8]), tr, i);
             if (ANYHIT) { if (inters) break; }
         }
 #ifdef CRT_PREFETCH_FAR
@@ -544,9 +550,6 @@ __device__ __forceinline__ bool tlas_candidates(const CrtDevScene& S, v3 o, v3 d
 // for all later instances. `anyHit` is the same boolean the full closest-hit loop would return, because until the
 // first passing triangle both visit the same nodes in the same order; only the work (and the counters) shrink.
 // ITERS (stamped diagnostic launches): the counters record wave-level trips instead of per-ray work.
-#ifndef CRT_SCALAR_INNER
-#define CRT_SCALAR_INNER 0     // 1: scalar fetch for wave-uniform nodes in both inner steps of a trip; 2: in the first only
-#endif
 template <bool COUNT, bool ITERS, bool ANYHIT, class STK>
 __device__ __forceinline__ void trip_steps(const CrtDevScene& S, const STK& stack, Traversal<COUNT>& T, Closest& c, LaneCounters& lc, bool done)
 {
