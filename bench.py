@@ -138,7 +138,7 @@ def pmc_valu(kernel, workload_scene, width, height, dev_s, clock_ghz, num_cus):
             d = json.load(open(path))
             b = d.get("bench_line") or {}
             dv = d.get("derived", {})
-            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene \
+            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene and not b["config"].get("diag_mix3") \
                     and b["config"].get("width") == width and b["config"].get("height") == height and "valu_insts_per_launch" in dv:
                 cyc = dev_s * clock_ghz * 1e9                     # cycles of device time per launch in this run
                 out = {"issue_busy": round(dv["valu_insts_per_launch"] * 2.0 / (4.0 * num_cus * cyc), 3),
@@ -159,6 +159,42 @@ def pmc_valu(kernel, workload_scene, width, height, dev_s, clock_ghz, num_cus):
     return None
 
 
+def pmc_vmem(kernel, workload_scene, width, height, dev_s, clock_ghz, num_cus):
+    """Vector-memory instruction budget of the dominant kernel: wave-level vector loads and L1 line accesses per launch from the
+    committed PMC passes over THIS run's device cycles per launch, next to what one such instruction costs the CU's vector-memory
+    path in tools/ubench/chain.hip (cycles per wave-hop / 4 loads / 32 waves per CU, by distinct lines per instruction)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            b = d.get("bench_line") or {}
+            dv = d.get("derived", {})
+            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene and not b["config"].get("diag_mix3") \
+                    and b["config"].get("width") == width and b["config"].get("height") == height and "vmem_rd_insts_per_launch" in dv:
+                cyc = dev_s * clock_ghz * 1e9
+                out = {"vector_loads_per_launch": int(dv["vmem_rd_insts_per_launch"]), "l1_lines_per_vector_load": round(dv.get("l1_lines_per_vmem_rd_inst", 0.0), 2),
+                       "cu_cycles_per_vector_load": round(cyc * num_cus / dv["vmem_rd_insts_per_launch"], 2), "source": os.path.relpath(path, ROOT),
+                       "note": "cu_cycles_per_vector_load = this run's device cycles per launch x CUs / vector loads per launch: the budget one wave-level "
+                               "load gets on its CU's vector-memory path with frames in flight; ubench_cost: what one dwordx4 load of a dependent chain costs "
+                               "that path in tools/ubench/chain.hip at 8 waves/SIMD, by distinct records per instruction"}
+                for cpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench_chain.json")), reverse=True):
+                    runs = [r for r in json.load(open(cpath))["runs"] if r["mix"].startswith("kernel mix") and r["waves_per_simd"] == 8]
+                    cost = {}
+                    for r in runs:
+                        v = r.get("variant", "")
+                        key = {"4 x dwordx4 (the kernel's)": f"{r['active_lanes']} lanes, a record each", "4 x dwordx4, 4 lanes/chain": "64 lanes, 16 records",
+                               "4 x dwordx4, 16 lanes/chain": "64 lanes, 4 records"}.get(v)
+                        if key and (v != "4 x dwordx4, 16 lanes/chain" or r["active_lanes"] == 64):
+                            # 8 waves/SIMD asked for, ~24.5 resident on average (the launch's extent / a wave's duration): use the rate, not the duration
+                            cost[key] = round(r["active_lanes"] / r["records_per_cycle_per_cu"] / 4.0, 1)
+                    out["ubench_cost_cycles_per_load"] = cost
+                    break
+                return out
+        except Exception:
+            continue
+    return None
+
+
 def pmc_traffic(kernel, workload_scene, width, height):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_summary.json:
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command, newest round first). FETCH_SIZE is exact
@@ -170,7 +206,7 @@ def pmc_traffic(kernel, workload_scene, width, height):
             d = json.load(open(path))
             b = d.get("bench_line") or {}
             c = d.get("counters", {})
-            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene \
+            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene and not b["config"].get("diag_mix3") \
                     and b["config"].get("width") == width and b["config"].get("height") == height and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((c["FETCH_SIZE"]["mean_per_launch"] + c["WRITE_SIZE"]["mean_per_launch"]) * 1024), os.path.relpath(path, ROOT)
         except Exception:
@@ -558,6 +594,7 @@ def main():
                                     "records_per_cycle_per_cu": round(gather_rate, 4),
                                     "uniform_l1_reference": round(GATHER_CEILING_UNIFORM, 4), "divergent_l2_reference": round(GATHER_DIVERGENT_L2, 4),
                                     "note": "reference points from tools/ubench/gather.hip (independent fetches): every lane on one L1-resident record / every lane on a different L2-resident record"},
+                         "vmem_pipe": pmc_vmem("crt_trace_kernel", sc.name, width, height, dev_s, clock_ghz, num_cus) if (n == 1 and not args.shadows) else None,
                          "valu": pmc_valu("crt_trace_kernel", sc.name, width, height, dev_s, clock_ghz, num_cus) if (n == 1 and not args.shadows) else None},
         }
         if warnings:
@@ -592,6 +629,10 @@ def main():
             s.set_camera(dense.camera_pos, dense.camera_front)
             out["dense_view"] = measure_view(s, flags, kx, f"multi-1M-dense: the same scene seen from among its instances, {width}x{height}")
             out["dense_view"]["synchronous_frames"] = measure_view(s, flags & ~4, kx, "same view, one frame at a time")["value"]
+            trd, srcd = pmc_traffic("crt_trace_kernel", "multi-1M-dense", width, height)
+            if trd:
+                out["dense_view"]["hbm"] = {"traffic": trd, "traffic_source": srcd, "achieved_gbs": round(trd / (out["dense_view"]["steady_state"]["ms_per_step"] * 1e-3) / 1e9, 1),
+                                            "frac": round(trd / (out["dense_view"]["steady_state"]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             s.set_camera(sc.camera_pos, sc.camera_front)
         if n == 1 and not args.width and not args.height and not args.no_config5:
             # the N = 1 point of BASELINE config 5 (the 3840x2160 frame the N > 1 lines tile over the ranks), so that a scaling

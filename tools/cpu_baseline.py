@@ -17,8 +17,18 @@ from clraytracer_amd import driver, scenes  # noqa: E402
 import oracle_lib  # noqa: E402
 
 cores = os.cpu_count() or 1
-threads = min(cores, 64)
-print(f"host: {cores} logical CPUs ({open('/proc/cpuinfo').read().split('model name')[1].split(':')[1].splitlines()[0].strip()}); using 1 and {threads} threads\n")
+affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+try:
+    quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+    cgroup = "unlimited" if quota == "max" else f"{float(quota) / float(period):.1f} CPUs ({quota}/{period} us)"
+    usable = affinity if quota == "max" else max(1, min(affinity, int(float(quota) / float(period))))
+except Exception:
+    cgroup, usable = "unknown", affinity
+threads = int(os.environ.get("CRT_CPU_THREADS", usable))       # the rule bench.py's cpu_baseline leg uses: the CPUs this process may actually use
+model = open('/proc/cpuinfo').read().split('model name')[1].split(':')[1].splitlines()[0].strip()
+print(f"host: {model}; {cores} logical CPUs, {affinity} in this process's affinity mask, cgroup CPU quota {cgroup} -> {usable} usable CPUs.")
+print(f"Rows are timed on 1 thread and on {threads} threads (= the usable CPUs; more threads than that are time-sliced by the quota and measure nothing new). "
+      f"bench.py's `cpu_baseline` object is the same experiment with the same thread rule: `cores` there = {threads} on this box.\n")
 print("| row | scene | frame | threads | time | Mrays/s |\n|---|---|---|---|---|---|")
 
 # C3 + C1 on cornell
@@ -45,8 +55,12 @@ with driver.Session(w, h, host_only=True) as s:
     rays = orc.raygen(w, h, iv, ip).reshape(-1, 3)
     origins = np.tile(pos, (len(rays), 1)).astype(np.float32)
     for nt in (1, threads):
-        t0 = time.perf_counter(); s.cpu_raycast(origins, rays, nthreads=nt); dt = time.perf_counter() - t0
-        print(f"| C1 CPU_RayCast | cornell-1k | 640x480 | {nt} | {dt * 1e3:.1f} ms | {len(rays) / dt / 1e6:.2f} |")
+        for sse in (False, True):
+            dt = None
+            for _ in range(5 if nt > 1 else 2):
+                t0 = time.perf_counter(); s.cpu_raycast(origins, rays, nthreads=nt, sse=sse); d = time.perf_counter() - t0
+                dt = d if dt is None else min(dt, d)
+            print(f"| C1 CPU_RayCast ({'SSE flavour: rcpps/dpps as upstream' if sse else 'scalar, IEEE divide'}) | cornell-1k | 640x480 | {nt} | {dt * 1e3:.1f} ms | {len(rays) / dt / 1e6:.2f} |")
 
 for name in ("cornell-1k", "sponza-class-250k", "multi-1M"):
     sc = scenes.get(name)
