@@ -32,6 +32,15 @@
 #include "../../include/crt_types.h"
 
 #define CRT_LEAF_BIT 0x80000000u
+#ifndef CRT_WAVE_OVF_TEST
+#define CRT_WAVE_OVF_TEST 1
+#endif
+#ifndef CRT_FLAT_CF
+#define CRT_FLAT_CF 1
+#endif
+#ifndef CRT_SELECT_SWAP
+#define CRT_SELECT_SWAP 1
+#endif
 #ifndef CRT_SCALAR_INNER
 #define CRT_SCALAR_INNER 1     // 1: scalar fetch for wave-uniform nodes in both inner steps of a trip; 2: in the first only; 0: never
 #endif
@@ -76,15 +85,24 @@ struct CrtStackT {
                                             // traversal loop it costs two VGPRs for the whole kernel
         return ovf + ((size_t)blockIdx.x * CRT_OVF_SLOTS_MAX + (size_t)k) * CRT_BLOCK + lane;
     }
+    // The overflow test is made for the WAVE first (one compare + one scalar branch): no scene here passes kLds entries in the
+    // common case, and the per-lane form costs every push and pop an exec-mask save / restore pair (the CU's scalar unit is
+    // ~66 % busy with such bookkeeping).
     __device__ __forceinline__ void write(int slot, uint32_t v) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
+#if CRT_WAVE_OVF_TEST
+        if (kLds >= CRT_STACK_DEPTH || __ballot(s >= kLds) == 0) { lds[s * 64] = v; return; }
+#endif
         if (kLds >= CRT_STACK_DEPTH || s < kLds) lds[s * 64] = v;
         else *overflow_slot(s - kLds) = v;
     }
     __device__ __forceinline__ uint32_t read(int slot) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
+#if CRT_WAVE_OVF_TEST
+        if (kLds >= CRT_STACK_DEPTH || __ballot(s >= kLds) == 0) return lds[s * 64];
+#endif
         if (kLds >= CRT_STACK_DEPTH || s < kLds) return lds[s * 64];
         return *overflow_slot(s - kLds);
     }
@@ -350,10 +368,24 @@ struct Traversal {
     template <class STK>
     __device__ __forceinline__ void pop_next(const STK& stack, Closest& c, LaneCounters& lc)
     {
+#if CRT_FLAT_CF
+        // the same decisions with one level of branching: `protection++` happens exactly when the stack is not empty
+        const bool nonEmpty = sp > 0, canPop = nonEmpty && prot < CRT_MAX_POPS;
+        prot += nonEmpty ? 1 : 0;
+        if (COUNT) { if (nonEmpty && !canPop) lc.capHits++; if (canPop) lc.pops++; }
+        if (canPop) { --sp; ref = stack.read(sp); }
+        else {
+            const bool keep = inters != 0;                       // finish(): selects instead of a nested branch
+            c.hitInstance = keep ? (int)curInst : c.hitInstance; c.distance = keep ? tr.t : c.distance; c.anyHit = keep ? 1 : c.anyHit;
+            c.hit.t = keep ? tr.t : c.hit.t; c.hit.u = keep ? tr.u : c.hit.u; c.hit.v = keep ? tr.v : c.hit.v; c.hit.tri = keep ? tr.tri : c.hit.tri;
+            active = false;
+        }
+#else
         if (sp > 0) {
             if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; finish(c); }
             else { if (COUNT) lc.pops++; --sp; ref = stack.read(sp); }
         } else finish(c);
+#endif
     }
     // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root
     // The instance record comes through a SCALAR load (one s_load_dwordx16 through the scalar cache) when every lane that
@@ -404,10 +436,30 @@ struct Traversal {
         asm volatile("" : "+v"(pf));      // the touch issued by an earlier step has landed by now (loads return in order): its register may be reused
 #endif
         uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
+#if CRT_SELECT_SWAP
+        {   // kernel_main.cl:148-151 as four selects on one compare (the branchy form costs an exec-mask save / restore)
+            const bool sw = dist1 > dist2;
+            const float d1 = sw ? dist2 : dist1, d2 = sw ? dist1 : dist2;
+            const uint32_t r1 = sw ? farRef : nearRef, r2 = sw ? nearRef : farRef;
+            dist1 = d1; dist2 = d2; nearRef = r1; farRef = r2;
+        }
+#else
         if (dist1 > dist2) {
             float tf = dist1; dist1 = dist2; dist2 = tf;
             uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
         }
+#endif
+#if CRT_FLAT_CF
+        if (dist2 != 1e30f) {                                   // both children hit (dist1 <= dist2): push the far one
+            if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
+            stack.write(sp, farRef);
+            sp++;
+            if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
+        }
+        if (dist1 == 1e30f) pop_next(stack, c, lc);
+        else ref = nearRef;
+        return;
+#endif
         if (dist1 == 1e30f) pop_next(stack, c, lc);
         else {
             ref = nearRef;
