@@ -1,0 +1,41 @@
+"""The occupancy the design rests on, checked without a GPU: hipcc cross-compiles crt_shim.hip for gfx950 with
+-Rpass-analysis=kernel-resource-usage (tools/kernel_resources.py does the same for people) and every PLAIN instantiation of the
+trace kernel -- crt_trace_kernel<COUNT=false, STAMP=false, SHADOW, TLAS, REFRACT>, the eight a frame without diagnostics can reach,
+BASELINE's "primary + shadow ray" configs and the 401-instance scenes included -- must fit 64 VGPRs with no scratch and 5 KiB of
+LDS: 8 waves per SIMD, 32 per CU. The register allocator is touchy here (an equivalent loop-exit test once cost
+30 spilled VGPRs), so this is a regression test for the build flags and the code shape, not for the GPU."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+def test_plain_trace_instantiations_need_no_scratch_and_64_vgprs():
+    flags = re.search(r"^HIPFLAGS = (.*)$", open(os.path.join(ROOT, "Makefile")).read(), re.M).group(1)
+    flags = flags.replace("$(ARCH)", "gfx950").split()
+    cmd = [HIPCC] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(ROOT, "clraytracer_amd/csrc/crt_shim.hip"), "-o", os.devnull]
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows, cur = {}, None
+    for line in p.stderr.splitlines():
+        m = re.search(r"remark: +Function Name: (\S+)", line)
+        if m:
+            name = subprocess.run(["c++filt", m.group(1)], stdout=subprocess.PIPE, text=True).stdout.strip()
+            cur = rows.setdefault(re.sub(r"\(.*", "", name).replace("void ", ""), {})
+            continue
+        m = re.search(r"remark: +([A-Za-z ]+?)(?: \[[a-zA-Z/]+\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    plain = {k: v for k, v in rows.items() if k.startswith("crt_trace_kernel<false, false,")}
+    assert len(plain) == 8, sorted(rows)
+    for name, r in plain.items():
+        assert r["ScratchSize"] == 0 and r["VGPRs"] <= 64 and r["AGPRs"] == 0 and r["Occupancy"] == 8 and r["LDS Size"] == 5120, (name, r)
+    # the instrumented instantiations may use more registers (6 waves/SIMD); the default counted and stamped ones must not spill either
+    assert rows["crt_trace_kernel<true, false, false, false, false>"]["ScratchSize"] == 0
+    assert rows["crt_trace_kernel<false, true, false, false, false>"]["ScratchSize"] == 0          # the stamped diagnostic launch
