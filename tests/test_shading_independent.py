@@ -176,3 +176,54 @@ def test_numpy_restatement_of_shading_matches_the_oracle(name, w, h, nthreads):
         assert np.nanmax(np.abs(got[differs & sky] - ref[..., :3][differs & sky])) <= 1.0
     assert np.array_equal(bits(ref[..., 3]), bits(np.ones((h, w), np.float32)))                                         # :274 (result, 1.0f)
     print(f"{name}: {st['hits']} shaded hit records, {st['misses']} skybox samples, {int(differs.sum())} pixels differ ({flips} skybox flips)")
+
+
+def postprocess_numpy(img):
+    """kernel PostProcess (kernel_main.cl:342-359) with Saturation / Reinhard / GammaCorrect / Vignette (MathAndSTL.cl:132-169) for a whole
+    float frame at once, written from that text: float32 throughout, sums in the order the source writes them, pow through float32 powf."""
+    h, w, _ = img.shape
+    rgb = np.ascontiguousarray(img[..., :3], np.float32).reshape(-1, 3).copy()
+    ys, xs = np.mgrid[0:h, 0:w]
+    uvx = (xs.reshape(-1).astype(np.float32)) / F(w)
+    uvy = (ys.reshape(-1).astype(np.float32)) / F(h)
+    # Saturation(rgb, 1.2f): P = sqrt(in.x*in.x*0.299f + (in.y*in.y*0.587f) + (in.z*in.z*0.114f)); P + (in - P) * change
+    P = np.sqrt((rgb[:, 0] * rgb[:, 0]) * F(0.299) + ((rgb[:, 1] * rgb[:, 1]) * F(0.587)) + ((rgb[:, 2] * rgb[:, 2]) * F(0.114)))
+    rgb = P[:, None] + (rgb - P[:, None]) * F(1.2)
+    # Reinhard: luminance-preserving extended Reinhard with max_white_l = 0.8, then pow(x, 1 / 1.55)
+    lw = np.array([[0.2126, 0.7152, 0.0722]], np.float32)
+    with np.errstate(all="ignore"):
+        l_old = dot3(rgb, np.broadcast_to(lw, rgb.shape))
+        numerator = l_old * (F(1.0) + (l_old / (F(0.8) * F(0.8))))
+        l_new = numerator / (F(1.0) + l_old)
+        l_in = dot3(rgb, np.broadcast_to(lw, rgb.shape))
+        rgb = rgb * (l_new / l_in)[:, None]
+        rgb = np.power(rgb, F(1.0) / F(1.55), dtype=np.float32)
+        rgb = np.power(rgb, F(1.0) / F(1.2), dtype=np.float32)                  # GammaCorrect
+        # Vignette(uv): uv *= 1 - uv.yx; vig = uv.x * uv.y * 15; pow(vig, 0.15)
+        vx, vy = uvx * (F(1.0) - uvy), uvy * (F(1.0) - uvx)
+        vig = np.power((vx * vy) * F(15.0), F(0.15), dtype=np.float32)
+    out = np.ones((h * w, 4), np.float32)
+    out[:, :3] = rgb * vig[:, None]
+    return out.reshape(h, w, 4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "sponza-sibenik"])
+def test_numpy_restatement_of_postprocess_matches_the_oracle(name, nthreads):
+    """SURVEY row a11 the same way: the oracle's PostProcess against a numpy restatement of the OpenCL text on real Trace frames (black pixels
+    included: their 0/0 makes NaN on both sides). Tolerance 2e-5 absolute -- the only difference between the two is the last place of three powf
+    calls per channel (numpy's float32 power versus glibc's powf), as between the oracle and the device (tests/test_gpu_parity.py)."""
+    w, h = 384, 216
+    sc = scenes.get(name)
+    with driver.Session(w, h, host_only=True) as s:
+        s.load_scene(sc)
+        a = {k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in s.arenas().items()}
+        iv, ip, pos = s.camera()
+    orc = oracle_lib.Oracle(a, nthreads=nthreads)
+    frame, _ = orc.trace(orc.raygen(w, h, iv, ip), pos, sc.sun_angle)
+    frame[0, :8, :3] = 0.0                                    # a few black pixels: Reinhard divides 0 by 0 (MathAndSTL.cl:137-141)
+    ref = orc.postprocess(frame)
+    got = postprocess_numpy(frame)
+    assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.isnan(ref[0, :8, :3]).all()
+    ok = ~np.isnan(ref)
+    assert np.max(np.abs(ref[ok] - got[ok])) <= 2e-5
+    assert (bits(ref)[ok] == bits(got)[ok]).mean() > 0.5      # most values agree to the bit; the rest differ in the last place of powf
