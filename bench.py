@@ -229,12 +229,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the 3840x2160 one-GPU point of the N = 1 line (profiling runs: it launches the same kernel at another size)")
     ap.add_argument("--no-extras", action="store_true", help="only the contract's timed region (+ synchronous frames): no config-5 point, no sub-records (A/B runs)")
+    ap.add_argument("--timed-region-only", action="store_true", help="profiling aid: after the warm-up run ONLY the contract's timed region (no synchronous leg, no clock-probe frames, "
+                                                                     "no extras), so that a kernel trace of the run holds launches of one mode only")
     ap.add_argument("--diag-mix3", action="store_true", help="profiling aid: every step is ONE dispatch tracing the frame three times with interleaved tile lists "
                                                              "(CRT_RENDER_DIAG_MIX3: the wave mix of three frames in flight, visible to a PMC pass); synchronous; rates are per 3 frames")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     if args.diag_mix3:
         args.frames_in_flight, args.no_extras, args.no_cpu_baseline = 1, True, True
+    if args.timed_region_only:
+        args.no_extras, args.no_cpu_baseline = True, True
     if args.no_extras:
         args.no_config5 = True
 
@@ -450,7 +454,7 @@ def main():
     # the same K frames the reference's way -- one at a time, Render() + clFinish (Renderer.cpp:305-367) -- reported
     # next to the headline as `synchronous_frames` (not part of the contract's timed region above)
     sync_elapsed = None
-    if flight > 1:
+    if flight > 1 and not args.timed_region_only:
         sflags = flags & ~4
         for _ in range(min(args.warmup, 3)):
             _lib.check(crt_render(p_args, p_iv, p_ip, sflags), "crt_render")
@@ -465,7 +469,7 @@ def main():
     # the shader clock the device holds while such frames are in flight: one probe wave per XCD watches s_memtime against the
     # 100 MHz s_memrealtime for 300 us on its own stream while 24 frames run (cycle-based figures below use this, not 2.4 GHz)
     clock_meas = None
-    if rank == 0:
+    if rank == 0 and not args.timed_region_only:
         for _ in range(24):
             crt_render(p_args, p_iv, p_ip, flags)
         ghz = C.c_double(0.0)

@@ -110,6 +110,11 @@ def main():
         f.write("## --kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
         for k in sorted(out["kernel_stats"], key=lambda r: -r["pct"]):
             f.write(f"| `{k['name'][:90]}` | {k['calls']} | {k['avg_ns'] / 1e3:.1f} | {k['min_ns'] / 1e3:.1f} | {k['max_ns'] / 1e3:.1f} | {k['pct']:.2f} |\n")
+        if out.get("launch_overlap") and out["bench_line"]:
+            km = out["bench_line"].get("kernel_ms", {})
+            f.write(f"\nThe same run's own HIP-event figures (bench.py, `kernel_ms`): mean launch duration {km.get('crt_trace_kernel_launch_mean', 0) * 1e3:.1f} us, "
+                    f"device time per frame {km.get('device_time_per_frame', 0) * 1e3:.1f} us -- to be read against the trace's figures in the next paragraph "
+                    f"(the trace also holds the 3 warm-up launches and the instrumented launch of another instantiation).\n")
         if out.get("launch_overlap"):
             o = out["launch_overlap"]
             f.write(f"\n`{kern}` launches in the trace: {o['launches']}, mean launch duration {o['mean_launch_us']:.1f} us, device time with at least one "

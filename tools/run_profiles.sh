@@ -9,7 +9,9 @@ mode=${2:-full}
 export TMPDIR=/tmp
 out=gpurun_out
 # --no-extras: the extra views / sizes would launch the timed region's kernel on other workloads and blur its per-launch means
-B="python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-extras $PROF_ARGS"
+# --timed-region-only: the trace then holds launches of the timed region's mode only (3 warm-up + 30 timed), so its average
+# duration can be read against the bench line's own HIP-event figure (kernel_ms.crt_trace_kernel_launch_mean) of the same run
+B="python3 bench.py --steps 30 --warmup 3 --timed-region-only $PROF_ARGS"
 S="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras $PROF_ARGS"
 pass() { # name, counters...
   local name=$1; shift
