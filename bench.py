@@ -9,7 +9,8 @@ scene that is already resident in HBM. By default three frames are in flight (CR
 k+1, k+2 are submitted while frame k runs, each on its own HIP stream and output buffer, so the long-ray
 tail of one frame is hidden behind the next; with N >= 4 ranks eight, because a rank's share of the
 frame shrinks and its slowest tile does not); all K frames are complete before the
-clock stops.
+clock stops. Before the W warm-up steps the scene is rendered for --prewarm-ms (untimed; 100 ms) so that the timed steps see the clocks a
+renderer runs at, not the ramp of the idle GPU the box hands over (`config.prewarm_ms`).
 `--frames-in-flight 1` gives the reference's Render()+clFinish per frame (Renderer.cpp:305-367).
 Workload:
   N == 1 : BASELINE config 4 -- `multi-1M` (8 meshes, 1,000,960 triangles, 16 instances, textures),
@@ -233,6 +234,7 @@ def main():
                                                                      "no extras), so that a kernel trace of the run holds launches of one mode only")
     ap.add_argument("--diag-mix3", action="store_true", help="profiling aid: every step is ONE dispatch tracing the frame three times with interleaved tile lists "
                                                              "(CRT_RENDER_DIAG_MIX3: the wave mix of three frames in flight, visible to a PMC pass); synchronous; rates are per 3 frames")
+    ap.add_argument("--prewarm-ms", type=float, default=100.0, help="untimed rendering before the warm-up steps, so that the timed steps do not measure the clock ramp of an idle GPU")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     if args.diag_mix3:
@@ -403,6 +405,14 @@ def main():
         single = (time.perf_counter() - t0) / 10
         s.set_row_bands(args.band_rows, rank, n)
 
+    # Clock pre-warm (untimed, before the W warm-up steps): the box hands over an idle GPU at its idle clocks, and W = 5 frames
+    # (1.5 ms) do not bring them up -- a 20-step timed region right behind them measured the DVFS ramp (5.85 ms of device time
+    # against 5.45 ms for the same burst repeated). Render for --prewarm-ms so the timed steps see the clocks a renderer runs at.
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(8):
+            _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
+        _lib.check(hip.crt_sync(), "crt_sync")
     for _ in range(args.warmup):
         _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
     _lib.check(hip.crt_sync(), "crt_sync")
@@ -562,7 +572,7 @@ def main():
                        "tiling": (f"16-row bands round-robin over {n} devices driven by ONE process (crt_init_devices {inproc_devices}), replicated scene, "
                                   "every frame gathered into device 0 by peer copies inside the timed region") if inproc
                                  else f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
-                       "frames_in_flight": flight, "control_plane": control_plane, "diag_mix3": bool(args.diag_mix3),
+                       "frames_in_flight": flight, "control_plane": control_plane, "diag_mix3": bool(args.diag_mix3), "prewarm_ms": args.prewarm_ms,
                        "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2),
                        "scene_load": ("max over ranks; meshes from the .clm caches rank 0 wrote once, BVH built on each GPU (crt_build_bvh)" if n > 1
                                       else "OBJ import (or .clm cache) + host SAH build + uploads")},

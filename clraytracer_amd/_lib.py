@@ -97,6 +97,7 @@ HIP_API = {
     "crt_get_counters": (C.c_int, [C.POINTER(CrtCounters)]),
     "crt_get_culled_visits": (C.c_int, [C.POINTER(C.c_uint64)]),
     "crt_debug_read_stamps": (C.c_int, [_vp, _sz, C.POINTER(C.c_size_t)]),
+    "crt_debug_read_frame_times": (C.c_int, [_vp, _sz, C.POINTER(C.c_size_t)]),
     "crt_error_string": (C.c_char_p, [C.c_int]),
     "crt_device_name": (C.c_char_p, []),
 }

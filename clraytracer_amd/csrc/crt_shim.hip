@@ -72,6 +72,11 @@ struct State {
     int cur = 0;                               // slot of the most recently submitted frame
     int readbackRing[CRT_MAX_FRAMES_IN_FLIGHT] = { -1, -1, -1, -1, -1, -1, -1, -1 }; unsigned readbackCount = 0;   // slots of the latest CRT_RENDER_READBACK frames
     unsigned asyncSeq = 0; bool othersBusy = false;   // frames possibly running on slots > 0
+    // Start-up stagger of a burst of frames in flight: frames submitted to an idle device start together, run in lockstep and have
+    // their long-ray tails at the same time -- exactly what frames in flight are there to avoid -- until the slots drift apart (three
+    // frames take 1.17 ms to fill the pipeline where steady state delivers 4.3). The first frame a slot runs after the session was
+    // idle is therefore held back on its stream by slot x (last frame latency / slots) by a one-wave timer kernel.
+    unsigned burstFrames = 0; int staggerUs = -1;   // frames submitted since the device was last known idle; CRT_STAGGER_US: -1 = automatic, 0 = off, n = n us per slot
     int width = 0, height = 0;
     int bandRows = 16, rank = 0, nRanks = 1;
     // raw (reference-layout) device copies
@@ -107,6 +112,7 @@ struct State {
     float ms[4] = { 0, 0, 0, 0 }; unsigned long long msSeq = 0, frameSeq = 0;   // timing of the newest frame read back so far
     hipEvent_t statStart = nullptr; bool statStartArmed = true, statStartValid = false; unsigned long long statStartSeq = 0; double statExtent = 0, statFirstMs = 0;
     CrtCounters lastCounters; unsigned long long lastCulled = 0;
+    double frameLog[512]; unsigned frameLogN = 0;      // crt_debug_read_frame_times: {start, end} ms after statStart of the frames since the last reset
     // in-process multi-GPU: this device renders band `rank` of `nRanks`; `primary` (rank 0) owns the frame that is read
     State* primary = nullptr; State* group[CRT_MAX_DEVICES] = { nullptr }; int groupSize = 1;
 };
@@ -133,7 +139,9 @@ int quiesce()
 int sync_all()
 {
     HIPCHK(hipStreamSynchronize(g.slot[0].stream));
-    return quiesce();
+    RCCHK(quiesce());
+    g.burstFrames = 0;                          // every slot is idle: the next pipelined frames start a burst
+    return CRT_OK;
 }
 
 int owned_tile_rows()
@@ -436,6 +444,10 @@ int collect_set(EventSet& es)
         HIPCHK(hipEventElapsedTime(&ext, g.statStart, frameEnd));
         if ((double)ext > g.statExtent) g.statExtent = (double)ext;
         if (es.seq == g.statStartSeq) g.statFirstMs = (double)ext;      // the first frame of the extent: fill time of the pipeline
+        if (g.frameLogN < 256) {
+            float st = 0;
+            if (hipEventElapsedTime(&st, g.statStart, ev[0]) == hipSuccess) { g.frameLog[2 * g.frameLogN] = (double)st; g.frameLog[2 * g.frameLogN + 1] = (double)ext; g.frameLogN++; }
+        }
     }
     if (es.seq >= g.msSeq) { memcpy(g.ms, ms, sizeof ms); g.msSeq = es.seq; }
     if (es.flags & CRT_RENDER_COUNTERS) {
@@ -537,6 +549,7 @@ static int init_impl(int device, int width, int height)
       if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
       else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
     { const char* e = getenv("CRT_TLAS"); g.forceTlas = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
+    { const char* e = getenv("CRT_STAGGER_US"); g.staggerUs = e ? atoi(e) : -1; }
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_FEEDBACK_ASYNC"); g.feedbackAsync = (e && atoi(e) != 0); }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
@@ -972,6 +985,14 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
     return CRT_OK;
 }
 
+// one wave that occupies its stream for `ticks` periods of the 100 MHz real-time counter (start-up stagger, see State::burstFrames)
+__global__ void crt_delay_kernel(unsigned long long ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long guard = 0;
+    while (__builtin_amdgcn_s_memrealtime() - r0 < ticks && guard < (1ull << 22)) { __builtin_amdgcn_s_sleep(16); ++guard; }
+}
+
 // In a multi-device session the dispatcher (crt_render) decides once per frame what every device must agree on and hands it
 // to each device's crt1_render: the frame slot (so a device that owned no rows of some frame, or failed one, cannot fall out
 // of step with the primary's slot rotation) and whether the call may return before the device has finished (secondaries
@@ -1066,8 +1087,17 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // A plain frame records only two (RayGen is fused, PostProcess off): [0] == [1], [2] == [3].
     if (g.statStartArmed) {                  // first frame since the statistics were reset: start of the extent
         HIPCHK(hipEventRecord(g.statStart, fs.stream));
-        g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0; g.statFirstMs = 0;
+        g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0; g.statFirstMs = 0; g.frameLogN = 0;
     }
+    if (pipelined) {
+        // first frame of this slot in a burst that starts from an idle device: hold it back so the slots do not run in lockstep
+        const unsigned k = g.burstFrames++;
+        if (k > 0 && k < (unsigned)g.nSlots && g.staggerUs != 0) {
+            double us = g.staggerUs > 0 ? (double)g.staggerUs * k : (double)g.ms[0] * 1e3 / (double)g.nSlots * k;   // g.ms[0]: latency of the newest frame timed so far
+            if (us > 2000.0) us = 2000.0;
+            if (us >= 5.0) { crt_delay_kernel<<<1, 64, 0, fs.stream>>>((unsigned long long)(us * 100.0)); HIPCHK(hipGetLastError()); }
+        }
+    } else g.burstFrames = 0;
     es.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
     es.evPost = (flags & (CRT_RENDER_POSTPROCESS | CRT_RENDER_UNORM8 | CRT_RENDER_FXAA)) != 0;
     HIPCHK(hipEventRecord(es.ev[0], fs.stream));
@@ -1381,6 +1411,16 @@ int crt1_frame_time_stats(CrtFrameStats* out, int reset)
         for (int k = 0; k < 4; ++k) g.msSum[k] = 0.0;
         g.framesTimed = 0; g.statExtent = 0; g.statFirstMs = 0; g.statStartArmed = true; g.statStartValid = false;
     }
+    return CRT_OK;
+}
+
+int crt1_debug_read_frame_times(double* dst, size_t maxFrames, size_t* numFrames)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!numFrames) return CRT_E_BAD_ARGUMENT;
+    RCCHK(collect_timing());
+    *numFrames = g.frameLogN;
+    if (dst) memcpy(dst, g.frameLog, sizeof(double) * 2 * (maxFrames < g.frameLogN ? maxFrames : g.frameLogN));
     return CRT_OK;
 }
 
@@ -1733,6 +1773,7 @@ int crt_frame_time_stats(CrtFrameStats* out, int reset)
     ON_PRIMARY(crt1_frame_time_stats(out, reset));
 }
 int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves) { ON_PRIMARY(crt1_debug_read_stamps(dst, maxWaves, numWaves)); }
+int crt_debug_read_frame_times(double* dst, size_t maxFrames, size_t* numFrames) { ON_PRIMARY(crt1_debug_read_frame_times(dst, maxFrames, numFrames)); }
 
 // work counters of the last counted frame: the sum over the devices (maxStack: the maximum)
 int crt_get_counters(CrtCounters* out)

@@ -195,6 +195,9 @@ int crt_get_culled_visits(uint64_t* out);
  * enter-instance steps | wave-level triangle iterations << 32, first-inner-step executions, leaf steps << 32 | lane-level node
  * visits}. Pass dst = NULL to query the wave count. */
 int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves);
+/* Diagnostic: {start, end} in ms after the start of the first frame, for each of the (up to 256) frames timed since the last
+ * crt_frame_time_stats(..., reset = 1), in the order their timing was collected: how a burst of frames in flight fills and drains. */
+int crt_debug_read_frame_times(double* dst, size_t maxFrames, size_t* numFrames);
 /* Diagnostic: the shader clock (GHz) the device holds under whatever load it carries while the call runs: one wave per XCD
  * watches s_memtime against the 100 MHz s_memrealtime for `micros` microseconds on a stream of its own (bench.py calls it
  * beside frames in flight so that cycle-based figures use the measured clock, not the 2.4 GHz nominal one). */
