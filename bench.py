@@ -147,7 +147,7 @@ def pmc_valu(kernel, workload_scene, width, height, dev_s, clock_ghz, num_cus):
                        "lane_utilisation": round(dv["valu_lane_utilisation"], 3),
                        "source": os.path.relpath(path, ROOT),
                        "note": "issue_busy = SQ_INSTS_VALU x 2 cycles (a wave64 instruction on a SIMD-32) / (SIMDs x this run's device cycles "
-                               "per launch at the nominal clock); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"}
+                               "per launch at the measured clock, roofline.chain.clock_ghz); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"}
                 if "l1_line_accesses_per_launch" in dv:
                     out["l1_line_accesses_per_cycle_per_cu"] = round(dv["l1_line_accesses_per_launch"] / (num_cus * cyc), 3)
                     out["l1_divergent_ceiling"] = round(256.0 / 181.0, 3)     # tools/ubench/gather.hip: 64 lanes x 4 loads on 64 distinct L2-resident lines in 181 cycles
