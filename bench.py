@@ -410,7 +410,7 @@ def main():
     # against 5.45 ms for the same burst repeated). Render for --prewarm-ms so the timed steps see the clocks a renderer runs at.
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-        for _ in range(8):
+        for _ in range(32):
             _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
         _lib.check(hip.crt_sync(), "crt_sync")
     for _ in range(args.warmup):

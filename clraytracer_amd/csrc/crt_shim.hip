@@ -76,6 +76,7 @@ struct State {
     // their long-ray tails at the same time -- exactly what frames in flight are there to avoid -- until the slots drift apart (three
     // frames take 1.17 ms to fill the pipeline where steady state delivers 4.3). The first frame a slot runs after the session was
     // idle is therefore held back on its stream by slot x (last frame latency / slots) by a one-wave timer kernel.
+    float pipelinedLatencyMs = 0.0f;     // latency of the newest plain frame-in-flight timed so far (what the stagger is derived from; 0 = none yet)
     unsigned burstFrames = 0; int staggerUs = -1;   // frames submitted since the device was last known idle; CRT_STAGGER_US: -1 = automatic, 0 = off, n = n us per slot
     int width = 0, height = 0;
     int bandRows = 16, rank = 0, nRanks = 1;
@@ -223,7 +224,7 @@ int alloc_frame_buffers(int w, int h)
         fs.out = outs[i];
         if (fs.aux) { (void)hipFree(fs.aux); fs.aux = nullptr; fs.auxPixels = 0; }
     }
-    g.width = w; g.height = h; g.readbackCount = 0;
+    g.width = w; g.height = h; g.readbackCount = 0; g.pipelinedLatencyMs = 0.0f;
     return CRT_OK;
 }
 
@@ -450,6 +451,7 @@ int collect_set(EventSet& es)
         }
     }
     if (es.seq >= g.msSeq) { memcpy(g.ms, ms, sizeof ms); g.msSeq = es.seq; }
+    if ((es.flags & CRT_RENDER_ASYNC) && !(es.flags & (CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS | CRT_RENDER_WRITE_RAYS))) g.pipelinedLatencyMs = ms[0];
     if (es.flags & CRT_RENDER_COUNTERS) {
         unsigned long long c[CRT_NUM_COUNTERS];
         HIPCHK(hipMemcpy(c, g.counters, sizeof c, hipMemcpyDeviceToHost));
@@ -1095,8 +1097,9 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         // (automatic only with up to three slots: with eight -- a rank's small share of a tiled frame, where one frame cannot fill the
         // GPU and the slots exist to run many at once -- the ramp costs more than the coinciding tails: 83.2 -> 74.6 Gray/s predicted at N = 8)
         if (k > 0 && k < (unsigned)g.nSlots && g.staggerUs != 0 && (g.staggerUs > 0 || g.nSlots <= 3)) {
-            double us = g.staggerUs > 0 ? (double)g.staggerUs * k : (double)g.ms[0] * 1e3 / (double)g.nSlots * k;   // g.ms[0]: latency of the newest frame timed so far
-            if (us > 2000.0) us = 2000.0;
+            double step = g.staggerUs > 0 ? (double)g.staggerUs : (double)g.pipelinedLatencyMs * 1e3 / (double)g.nSlots;
+            if (step > 500.0) step = 500.0;                      // a stale or foreign latency must not stall a burst
+            const double us = step * k;
             if (us >= 5.0) { crt_delay_kernel<<<1, 64, 0, fs.stream>>>((unsigned long long)(us * 100.0)); HIPCHK(hipGetLastError()); }
         }
     } else g.burstFrames = 0;
