@@ -190,6 +190,13 @@ def pmc_vmem(kernel, workload_scene, width, height, dev_s, clock_ghz, num_cus):
                             cost[key] = round(r["active_lanes"] / r["records_per_cycle_per_cu"] / 4.0, 1)
                     out["ubench_cost_cycles_per_load"] = cost
                     break
+                for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench_chain_pmc.json")), reverse=True):
+                    fit = json.load(open(ppath))["fit"]
+                    model = fit["cycles_per_load"] + fit["cycles_per_line"] * dv.get("l1_lines_per_vmem_rd_inst", 0.0)
+                    out["busy_modelled"] = round(model / out["cu_cycles_per_vector_load"], 3)
+                    out["busy_model"] = (f"({fit['cycles_per_load']:.1f} + {fit['cycles_per_line']:.2f} x L1 lines per load) cycles per vector load -- the line through the chain microbenchmark's "
+                                         f"PMC passes, where TA/TD are 86-98 % busy ({os.path.relpath(ppath, ROOT)}) -- over cu_cycles_per_vector_load")
+                    break
                 return out
         except Exception:
             continue

@@ -163,7 +163,10 @@ int main(int argc, char** argv)
                           { "all records from L2", 0.0f, 1.0f },
                           { "all records from the Infinity Cache", 0.0f, 0.0f } };
     std::vector<float> host((size_t)TOTAL_RECS * 16);
-    FILE* js = argc > 1 ? fopen(argv[1], "w") : nullptr;
+    // --brief: only the kernel's mix at 8 waves/SIMD (64 and 28 chasing lanes, 16 lanes per chain) -- the runs a PMC pass of this binary is
+    // read for (tools/ubench_pmc.sh: is the vector-memory path saturated at the ceiling?)
+    const bool brief = argc > 1 && strcmp(argv[1], "--brief") == 0;
+    FILE* js = (argc > 1 && !brief) ? fopen(argv[1], "w") : nullptr;
     if (js) fprintf(js, "{\"device\": \"%s\", \"cus\": %d, \"runs\": [\n", prop.gcnArchName, numCus);
     bool firstJs = true;
     printf("%s, %d CUs; every wave 64-thread workgroup with 5 KiB LDS, launch_bounds(64, 8); hops per lane 512\n", prop.gcnArchName, numCus);
@@ -192,6 +195,13 @@ int main(int argc, char** argv)
                 firstJs = false;
             }
         };
+        if (brief) {
+            if (&m != &mixes[0]) break;
+            report("4 x dwordx4 (the kernel's)", 8, 64, run<4, 1>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+            report("4 x dwordx4 (the kernel's)", 8, 28, run<4, 1>(dRecs, numCus * 32, 512, 28, dOut, dStamps, numCus));
+            report("4 x dwordx4, 16 lanes/chain", 8, 64, run<4, 16>(dRecs, numCus * 32, 512, 64, dOut, dStamps, numCus));
+            continue;
+        }
         for (int wps : { 8, 4, 2, 1 })
             for (uint32_t lanes : { 64u, 28u }) report("4 x dwordx4 (the kernel's)", wps, lanes, run<4, 1>(dRecs, numCus * 4 * wps, 512, lanes, dOut, dStamps, numCus));
         // diagnostics at full occupancy: fewer loads per record, shared chains
