@@ -48,3 +48,24 @@ def test_two_ranks_under_torch_distributed_run():
     assert d["config"]["control_plane"] == "gloo"                           # the rehearsal never uses RCCL (both ranks sit on GPU 0)
     assert d["delivered_to_host"]["value"] > 0 and d["delivered_to_host_rgba8"]["value"] > 0
     assert "16-row bands round-robin over 2 rank(s)" in d["config"]["tiling"]
+
+
+def test_single_gpu_line_carries_the_contract_and_the_round_3_objects():
+    """The N = 1 line the driver records: the contract's keys, the roofline object against the ceiling that binds (with the HBM
+    figure beside it), the sub-records for BASELINE's literal and hard configurations, and the CPU baseline incl. config 1."""
+    d = run_bench([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--prewarm-ms", "10"], {"CRT_BENCH_REHEARSE": "0"})
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["scene"] == "multi-1M" and d["config"]["width"] == 1920 and "workload" in d["config"] and d["config"]["prewarm_ms"] == 10
+    r = d["roofline"]
+    assert r["chain"] is not None and 0 < r["frac"] == r["chain"]["frac"] and r["peak"] == r["chain"]["ceiling"] and 0.5 < r["chain"]["clock_ghz"] < 2.6
+    assert r["hbm"]["peak"] == 8000.0 and (r["hbm_frac"] is None or 0 < r["hbm_frac"] <= 1.0) and r["traffic"] is None or r["traffic"] > 0
+    assert r["vmem_pipe"] is None or 0 < r["vmem_pipe"]["busy_modelled"] < 1.5
+    for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "config5_one_gpu"):
+        assert d[key]["value"] > 0 and d[key]["rays_per_frame"] > 0, key
+    assert d["with_shadow_rays"]["shadow_rays_per_frame"] > 0 and d["dense_view"]["primary_hit_fraction"] > 0.9
+    assert d["steady_state"]["value"] > 0 and d["synchronous_frames"]["value"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["primary_hits_consistent"] and c["trace_oracle"]["rays_match_gpu"]
+    assert c["config1_cornell_1k_640x480"]["value"] > 0 and c["config1_cornell_1k_640x480"]["primary_hits"] > 0
