@@ -227,3 +227,29 @@ def test_numpy_restatement_of_postprocess_matches_the_oracle(name, nthreads):
     ok = ~np.isnan(ref)
     assert np.max(np.abs(ref[ok] - got[ok])) <= 2e-5
     assert (bits(ref)[ok] == bits(got)[ok]).mean() > 0.5      # most values agree to the bit; the rest differ in the last place of powf
+
+
+def test_numpy_restatement_of_raygen_matches_the_oracle():
+    """SURVEY row a1 (kernel_main.cl:277-287): coord = (i / W, j / H) * 2 - 1; target = invProj . (coord, 1, 1); target /= target.w;
+    dir = normalize((invView . target).xyz) -- MatMul in the row-vector convention of MathAndSTL.cl:100-102, every sum left to right."""
+    w, h = 640, 360
+    sc = scenes.get("tiny")
+    with driver.Session(w, h, host_only=True) as s:
+        s.load_scene(sc)
+        a = {k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in s.arenas().items()}
+        iv, ip, pos = s.camera()
+    ref = oracle_lib.Oracle(a, nthreads=2).raygen(w, h, iv, ip)
+    ivm, ipm = np.asarray(iv, np.float32).reshape(4, 4), np.asarray(ip, np.float32).reshape(4, 4)
+    jj, ii = np.mgrid[0:h, 0:w]
+    cx = (ii.astype(np.float32) / F(w)) * F(2.0) - F(1.0)
+    cy = (jj.astype(np.float32) / F(h)) * F(2.0) - F(1.0)
+
+    def matmul(m, x, y, z, wv):          # m.x * v.xxxx + m.y * v.yyyy + m.z * v.zzzz + m.w * v.wwww
+        return [((m[0, c] * x + m[1, c] * y) + m[2, c] * z) + m[3, c] * wv for c in range(4)]
+    one = np.ones_like(cx)
+    t = matmul(ipm, cx, cy, one, one)
+    t = [t[0] / t[3], t[1] / t[3], t[2] / t[3], t[3] / t[3]]
+    v = matmul(ivm, *t)
+    inv = F(1.0) / np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+    got = np.stack([v[0] * inv, v[1] * inv, v[2] * inv], axis=-1).astype(np.float32)
+    assert np.array_equal(bits(got), bits(ref))
