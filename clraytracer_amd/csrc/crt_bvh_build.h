@@ -354,6 +354,238 @@ __global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, const uint32
     }
 }
 
+// ---- MID nodes (9 .. CRT_BVH_SMALL triangles), one WAVE per node and CRT_BVH_WAVES nodes per workgroup ----
+// One workgroup per node (r2) made the deep levels dispatch- and atomic-bound: 45,000 one-wave workgroups per launch, three
+// launches per level, and one same-address returning atomic per node (~6.7 ns each: 300 us of a 550 us partition launch).
+// Here a wave does UpdateNodeBounds / FindBestSplitPlane + the partition of its node with wave-level reductions only, the
+// 21 candidate planes are evaluated by 21 lanes instead of one thread, and the workgroup's waves share ONE atomic.
+#define CRT_BVH_WAVES 8
+#define CRT_BVH_LDS_TABLE 128         // partition tables of nodes up to this size live in LDS, larger ones in the global scratch
+__device__ __forceinline__ uint32_t bvh_wave_min(uint32_t v) { for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o < v ? o : v; } return v; }
+__device__ __forceinline__ uint32_t bvh_wave_max(uint32_t v) { for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o > v ? o : v; } return v; }
+__device__ __forceinline__ int bvh_wave_max_i(int v) { for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o > v ? o : v; } return v; }
+// what one lane wrote (LDS or global) is read by another lane of the same wave after this
+__device__ __forceinline__ void bvh_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// UpdateNodeBounds (BVH.cpp:54-74) for the nodes list[0 .. count): same reductions as crt_bvh_bounds, per wave.
+__global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_bounds_wave(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, const CrtTri* __restrict__ tris)
+{
+    const uint32_t k = blockIdx.x * CRT_BVH_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= count) return;                                   // whole waves leave; no workgroup barrier below
+    CrtBuildNode& node = nodes[list[k]];
+    const uint32_t first = node.first, n = node.count;
+    float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+    for (uint32_t i = lane; i < n; i += 64) {
+        const float* t = bvh_tri_f(tris, (size_t)first + i);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float x = t[4 * v + c]; mn[c] = mn[c] < x ? mn[c] : x; mx[c] = mx[c] > x ? mx[c] : x; }
+    }
+    float rmin[3], rmax[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { rmin[c] = bvh_unordered(bvh_wave_min(bvh_ordered(mn[c]))); rmax[c] = bvh_unordered(bvh_wave_max(bvh_ordered(mx[c]))); }
+    bool anyZero = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) anyZero = anyZero || rmin[c] == 0.0f || rmax[c] == 0.0f;
+    if (anyZero) {                                            // the sign of a zero bound: the last zero in sequence order (see crt_bvh_bounds)
+        int last[6] = { -1, -1, -1, -1, -1, -1 };
+        for (uint32_t i = lane; i < n; i += 64) {
+            const float* t = bvh_tri_f(tris, (size_t)first + i);
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (t[4 * v + c] == 0.0f) {
+                        const int s = (int)(i * 3 + v);
+                        if (rmin[c] == 0.0f) last[c] = last[c] > s ? last[c] : s;
+                        if (rmax[c] == 0.0f) last[3 + c] = last[3 + c] > s ? last[3 + c] : s;
+                    }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int a = bvh_wave_max_i(last[c]), b = bvh_wave_max_i(last[3 + c]);
+            if (rmin[c] == 0.0f && a >= 0) rmin[c] = bvh_tri_f(tris, (size_t)first + a / 3)[4 * (a % 3) + c];
+            if (rmax[c] == 0.0f && b >= 0) rmax[c] = bvh_tri_f(tris, (size_t)first + b / 3)[4 * (b % 3) + c];
+        }
+    }
+    if (lane == 0)
+        for (int c = 0; c < 3; ++c) { node.bmin[c] = rmin[c]; node.bmax[c] = rmax[c]; }
+}
+
+// FindBestSplitPlane + the split decision + the partition (BVH.cpp:103-163, 165-216) for the nodes list[0 .. count).
+__global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_mid(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count,
+                                                                  CrtTri* __restrict__ src, CrtTri* __restrict__ dst, uint32_t poolFirst,
+                                                                  uint32_t* __restrict__ rank, uint32_t* __restrict__ holes, uint32_t* __restrict__ backL,
+                                                                  uint32_t levelEnd, unsigned long long* __restrict__ packed, CrtBuildLists next)
+{
+    __shared__ uint32_t s_cnt[CRT_BVH_WAVES][3][CRT_BVH_BINS];
+    __shared__ uint32_t s_bmin[CRT_BVH_WAVES][3][CRT_BVH_BINS][3], s_bmax[CRT_BVH_WAVES][3][CRT_BVH_BINS][3];
+    __shared__ uint32_t s_tab[CRT_BVH_WAVES][3][CRT_BVH_LDS_TABLE];
+    __shared__ unsigned long long s_inc[CRT_BVH_WAVES];
+    __shared__ unsigned long long s_base;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t k = blockIdx.x * CRT_BVH_WAVES + w;
+    const bool live = k < count;                              // wave-uniform
+    CrtBuildNode& node = nodes[list[live ? k : 0]];
+    const uint32_t first = node.first, n = node.count;
+    unsigned long long inc = 0; uint32_t L = 0;
+    if (live) {
+        for (int j = lane; j < 3 * CRT_BVH_BINS; j += 64) (&s_cnt[w][0][0])[j] = 0;
+        for (int j = lane; j < 9 * CRT_BVH_BINS; j += 64) { (&s_bmin[w][0][0][0])[j] = bvh_ordered(1e30f); (&s_bmax[w][0][0][0])[j] = bvh_ordered(-1e30f); }
+        float cmin[3], cmax[3];
+        {
+            float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+            for (uint32_t i = lane; i < n; i += 64)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { const float v = bvh_centroid(src, (size_t)first + i, a); mn[a] = mn[a] < v ? mn[a] : v; mx[a] = mx[a] > v ? mx[a] : v; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { cmin[a] = bvh_unordered(bvh_wave_min(bvh_ordered(mn[a]))); cmax[a] = bvh_unordered(bvh_wave_max(bvh_ordered(mx[a]))); }
+        }
+        bvh_wave_sync();
+        for (uint32_t i = lane; i < n; i += 64) {
+            const float* t = bvh_tri_f(src, (size_t)first + i);
+            float tmn[3], tmx[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float lo = 1e30f, hi = -1e30f;
+#pragma unroll
+                for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; lo = lo < x ? lo : x; hi = hi > x ? hi : x; }
+                tmn[c] = lo; tmx[c] = hi;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (cmax[a] == cmin[a]) continue;
+                const float scale = (float)CRT_BVH_BINS / (cmax[a] - cmin[a]);
+                int b = f2i((t[3 + 4 * a] - cmin[a]) * scale);
+                b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
+                if (b < 0) b = 0;
+                atomicAdd(&s_cnt[w][a][b], 1u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { atomicMin(&s_bmin[w][a][b][c], bvh_ordered(tmn[c])); atomicMax(&s_bmax[w][a][b][c], bvh_ordered(tmx[c])); }
+            }
+        }
+        bvh_wave_sync();
+        // the sweep (BVH.cpp:131-160), one lane per candidate plane: lane = 7 * axis + plane. Growing the bin boxes in sweep order is a
+        // min/max over the non-empty bins on that side, so a lane can form its two boxes on its own; `planeCost < bestCost` taken in
+        // sequence order keeps the FIRST plane that reaches the minimum = the lexicographic minimum of (cost, lane); a NaN cost (an
+        // empty side: 0 x Inf) or one that is not below the initial 1e30 never wins.
+        float cost = 1e30f, myPos = 0.0f; uint32_t idx = 64u + lane;
+        if (lane < 3 * (CRT_BVH_BINS - 1)) {
+            const int a = (int)lane / (CRT_BVH_BINS - 1), p = (int)lane % (CRT_BVH_BINS - 1);
+            const float lo = a == 0 ? cmin[0] : (a == 1 ? cmin[1] : cmin[2]), hi = a == 0 ? cmax[0] : (a == 1 ? cmax[1] : cmax[2]);
+            if (!(hi == lo)) {
+                int leftSum = 0, rightSum = 0;
+                float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
+                float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
+                for (int i = 0; i < CRT_BVH_BINS; ++i) {
+                    const int c_ = (int)s_cnt[w][a][i];
+                    float bmn[3], bmx[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { bmn[c] = bvh_unordered(s_bmin[w][a][i][c]); bmx[c] = bvh_unordered(s_bmax[w][a][i][c]); }
+                    const bool grow = bmn[0] != 1e30f;       // aabb::grow(aabb) (BVH.cpp:29-37): skipped for an empty box
+                    if (i <= p) {
+                        leftSum += c_;
+                        if (grow)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                lmn[c] = lmn[c] < bmn[c] ? lmn[c] : bmn[c]; lmx[c] = lmx[c] > bmn[c] ? lmx[c] : bmn[c];
+                                lmn[c] = lmn[c] < bmx[c] ? lmn[c] : bmx[c]; lmx[c] = lmx[c] > bmx[c] ? lmx[c] : bmx[c];
+                            }
+                    } else {
+                        rightSum += c_;
+                        if (grow)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                rmn[c] = rmn[c] < bmn[c] ? rmn[c] : bmn[c]; rmx[c] = rmx[c] > bmn[c] ? rmx[c] : bmn[c];
+                                rmn[c] = rmn[c] < bmx[c] ? rmn[c] : bmx[c]; rmx[c] = rmx[c] > bmx[c] ? rmx[c] : bmx[c];
+                            }
+                    }
+                }
+                const float planeCost = (float)leftSum * bvh_area(lmn, lmx) + (float)rightSum * bvh_area(rmn, rmx);
+                const float scale = (hi - lo) / (float)CRT_BVH_BINS;
+                myPos = lo + scale * (float)(p + 1);
+                if (planeCost < 1e30f) { cost = planeCost; idx = lane; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float oc = __shfl_xor(cost, off, 64); const uint32_t oi = (uint32_t)__shfl_xor((int)idx, off, 64);
+            if (oc < cost || (oc == cost && oi < idx)) { cost = oc; idx = oi; }
+        }
+        const bool found = idx < 3u * (CRT_BVH_BINS - 1);
+        const float splitPos = found ? __shfl(myPos, (int)(found ? idx : 0u), 64) : 0.0f;
+        const int axis = found ? (int)idx / (CRT_BVH_BINS - 1) : 0;
+        const float bestCost = found ? cost : 1e30f;
+        const float nosplitCost = (float)n * bvh_area(node.bmin, node.bmax);
+        const bool isLeaf = bestCost >= nosplitCost;
+        if (lane == 0) { node.axis = axis; node.splitPos = splitPos; node.state = isLeaf ? 2u : 1u; }
+        if (isLeaf) {                                          // same order in both buffers
+            for (uint32_t i = lane; i < n; i += 64) bvh_copy_tri(dst, (size_t)first + i, src, (size_t)first + i);
+        } else {
+            // the partition in its closed form (see the header and crt_bvh_partition), ballots instead of workgroup scans
+            const bool inLds = n <= CRT_BVH_LDS_TABLE;
+            uint32_t* rk = inLds ? s_tab[w][0] : rank + (first - poolFirst);
+            uint32_t* hl = inLds ? s_tab[w][1] : holes + (first - poolFirst);
+            uint32_t* bl = inLds ? s_tab[w][2] : backL + (first - poolFirst);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            for (uint32_t base = 0; base < n; base += 64) {
+                const uint32_t x = base + lane;
+                L += (uint32_t)__popcll(__ballot(x < n && bvh_centroid(src, (size_t)first + x, axis) < splitPos));
+            }
+            uint32_t G = 0;
+            for (uint32_t base = 0; base < L; base += 64) {
+                const uint32_t x = base + lane;
+                const bool isR = x < L && !(bvh_centroid(src, (size_t)first + x, axis) < splitPos);
+                const unsigned long long m = __ballot(isR);
+                const uint32_t r = G + (uint32_t)__popcll(m & below);
+                if (isR) { rk[x] = r; hl[r] = x; }
+                G += (uint32_t)__popcll(m);
+            }
+            uint32_t GB = 0;
+            const uint32_t nb = n - L;
+            for (uint32_t base = 0; base < nb; base += 64) {
+                const uint32_t y = base + lane;
+                const bool isL = y < nb && (bvh_centroid(src, (size_t)first + (n - 1 - y), axis) < splitPos);
+                const unsigned long long m = __ballot(isL);
+                const uint32_t r = GB + (uint32_t)__popcll(m & below);
+                if (isL) { rk[n - 1 - y] = r; bl[r] = y; }
+                GB += (uint32_t)__popcll(m);
+            }
+            bvh_wave_sync();                                  // tables complete (G == GB by counting)
+            for (uint32_t x = lane; x < n; x += 64) {
+                const bool isLeft = bvh_centroid(src, (size_t)first + x, axis) < splitPos;
+                uint32_t dest;
+                if (x < L) {
+                    if (isLeft) dest = x;
+                    else { const uint32_t m = rk[x]; const uint32_t slot = m == 0 ? 0u : bl[m - 1] + 1u; dest = n - 1 - slot; }
+                } else if (isLeft) dest = hl[rk[x]];
+                else if (x == L) { const uint32_t slot = G == 0 ? 0u : bl[G - 1] + 1u; dest = n - 1 - slot; }
+                else dest = x - 1;
+                bvh_copy_tri(dst, (size_t)first + dest, src, (size_t)first + x);
+            }
+            if (L == 0 || L == n) {                           // BVH.cpp:194: stays a leaf, triangles stay permuted -> both buffers
+                bvh_wave_sync();
+                for (uint32_t i = lane; i < n; i += 64) bvh_copy_tri(src, (size_t)first + i, dst, (size_t)first + i);
+                if (lane == 0) node.state = 3u;
+            } else inc = bvh_pack_one(bvh_class(L)) + bvh_pack_one(bvh_class(n - L));
+        }
+    }
+    // one atomic per workgroup for the children of its CRT_BVH_WAVES nodes
+    if (lane == 0) s_inc[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0;
+        for (int j = 0; j < CRT_BVH_WAVES; ++j) total += s_inc[j];
+        s_base = total ? atomicAdd(packed, total) : 0ull;
+    }
+    __syncthreads();
+    if (inc != 0 && lane == 0) {
+        unsigned long long before = s_base;
+        for (uint32_t j = 0; j < w; ++j) before += s_inc[j];
+        bvh_new_children(nodes, node, first, L, n, levelEnd, before, next);
+    }
+}
+
 // UpdateNodeBounds for TINY nodes: one thread per node, the sequential fold itself.
 __global__ void crt_bvh_bounds_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, const CrtTri* __restrict__ tris)
 {

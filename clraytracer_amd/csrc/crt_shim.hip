@@ -788,7 +788,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
 
     auto bounds = [&](const CrtBuildLists& L, const uint32_t n[3], const CrtTri* tris) {
         if (n[0]) crt_bvh_bounds<<<n[0], 1024, 0, st>>>(bn, L.list[0], tris);
-        if (n[1]) crt_bvh_bounds<<<n[1], 64, 0, st>>>(bn, L.list[1], tris);
+        if (n[1]) crt_bvh_bounds_wave<<<(n[1] + CRT_BVH_WAVES - 1) / CRT_BVH_WAVES, 64 * CRT_BVH_WAVES, 0, st>>>(bn, L.list[1], n[1], tris);
         if (n[2]) crt_bvh_bounds_tiny<<<(n[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], n[2], tris);
     };
     bounds(lists[0], cnt, A);
@@ -803,8 +803,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         HIPCHK(hipMemsetAsync(dPacked, 0, sizeof hp, st));
         if (cnt[0]) { crt_bvh_split<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src);
                       crt_bvh_partition<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src, dst, (uint32_t)firstTri, rank, holes, backL, end, dPacked, N); }
-        if (cnt[1]) { crt_bvh_split<<<cnt[1], 64, 0, st>>>(bn, L.list[1], src);
-                      crt_bvh_partition<<<cnt[1], 64, 0, st>>>(bn, L.list[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, dPacked, N); }
+        if (cnt[1]) crt_bvh_mid<<<(cnt[1] + CRT_BVH_WAVES - 1) / CRT_BVH_WAVES, 64 * CRT_BVH_WAVES, 0, st>>>(bn, L.list[1], cnt[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, dPacked, N);
         if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, dPacked, N);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&hp, dPacked, sizeof hp, hipMemcpyDeviceToHost, st));
