@@ -60,24 +60,10 @@ __global__ void crt_bvh_centroids(CrtTri* __restrict__ tris, size_t first, size_
     t[11] = ((t[2] + t[6]) + t[10]) * 0.333333f;
 }
 
-__global__ void crt_bvh_init_roots(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ meshTriCounts, int numMeshes, uint32_t firstTri)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t cur = firstTri;
-    for (int m = 0; m < numMeshes; ++m) {
-        CrtBuildNode n;
-        n.first = cur; n.count = meshTriCounts[m]; n.left = n.right = CRT_BVH_NONE;
-        for (int c = 0; c < 3; ++c) { n.bmin[c] = 1e30f; n.bmax[c] = -1e30f; }
-        n.splitPos = 0.0f; n.axis = 0; n.state = 0; n.desc = 0; n.index = 0; n.base = 0; n.pad = 0;
-        nodes[m] = n;
-        cur += meshTriCounts[m];
-    }
-}
-
-// The nodes of one level are kept in three compact id lists by size: BIG (> CRT_BVH_SMALL triangles) and MID nodes get
-// one workgroup each (1024 / 64 threads) running the parallel formulation; TINY nodes (<= CRT_BVH_TINY triangles -- the
-// bulk of the deep levels: the builder splits down to one or two triangles per leaf) get one THREAD each that replays
-// upstream's sequential code literally (crt_bvh_tiny).
+// The nodes of one level are kept in three compact id lists by size: BIG nodes (> CRT_BVH_SMALL triangles) are cut into chunks of
+// CRT_BVH_CHUNK triangles, one workgroup per chunk (crt_bvh_big_*); MID nodes get one wave each (crt_bvh_bounds_wave, crt_bvh_mid);
+// TINY nodes (<= CRT_BVH_TINY triangles -- the bulk of the deep levels: the builder splits down to one or two triangles per leaf) get
+// one THREAD each that replays upstream's sequential code literally (crt_bvh_tiny).
 #define CRT_BVH_SMALL 2048
 #ifndef CRT_BVH_TINY
 #define CRT_BVH_TINY 8
@@ -117,150 +103,67 @@ __device__ __forceinline__ void bvh_new_children(CrtBuildNode* nodes, CrtBuildNo
     next.list[cr][bvh_unpack(before + bvh_pack_one(cl), cr)] = id + 1;
 }
 
-// UpdateNodeBounds (BVH.cpp:54-74) for the nodes list[0 .. gridDim.x).
-__global__ void crt_bvh_bounds(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtTri* __restrict__ tris)
-{
-    CrtBuildNode& node = nodes[list[blockIdx.x]];
-    __shared__ uint32_t s_min[3], s_max[3];
-    __shared__ int s_last[6];
-    const uint32_t first = node.first, n = node.count;
-    if (threadIdx.x < 3) { s_min[threadIdx.x] = bvh_ordered(1e30f); s_max[threadIdx.x] = bvh_ordered(-1e30f); }
-    if (threadIdx.x < 6) s_last[threadIdx.x] = -1;
-    __syncthreads();
-    float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float* t = bvh_tri_f(tris, (size_t)first + i);
-#pragma unroll
-        for (int v = 0; v < 3; ++v)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { const float x = t[4 * v + c]; mn[c] = mn[c] < x ? mn[c] : x; mx[c] = mx[c] > x ? mx[c] : x; }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { atomicMin(&s_min[c], bvh_ordered(mn[c])); atomicMax(&s_max[c], bvh_ordered(mx[c])); }
-    __syncthreads();
-    float rmin[3], rmax[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { rmin[c] = bvh_unordered(s_min[c]); rmax[c] = bvh_unordered(s_max[c]); }
-    // sign of a zero bound: the sequential fold `acc < x ? acc : x` keeps the LAST zero it meets (tris in order, v0 v1 v2)
-    bool anyZero = false;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) anyZero = anyZero || rmin[c] == 0.0f || rmax[c] == 0.0f;
-    if (anyZero) {
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const float* t = bvh_tri_f(tris, (size_t)first + i);
-            for (int v = 0; v < 3; ++v)
-                for (int c = 0; c < 3; ++c)
-                    if (t[4 * v + c] == 0.0f) {
-                        if (rmin[c] == 0.0f) atomicMax(&s_last[c], (int)(i * 3 + v));
-                        if (rmax[c] == 0.0f) atomicMax(&s_last[3 + c], (int)(i * 3 + v));
-                    }
-        }
-        __syncthreads();
-        for (int c = 0; c < 3; ++c) {
-            if (rmin[c] == 0.0f && s_last[c] >= 0) rmin[c] = bvh_tri_f(tris, (size_t)first + s_last[c] / 3)[4 * (s_last[c] % 3) + c];
-            if (rmax[c] == 0.0f && s_last[3 + c] >= 0) rmax[c] = bvh_tri_f(tris, (size_t)first + s_last[3 + c] / 3)[4 * (s_last[3 + c] % 3) + c];
-        }
-    }
-    if (threadIdx.x == 0)
-        for (int c = 0; c < 3; ++c) { node.bmin[c] = rmin[c]; node.bmax[c] = rmax[c]; }
-}
+// wave-level reductions on ordered images / indices
+__device__ __forceinline__ uint32_t bvh_wave_min(uint32_t v) { for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o < v ? o : v; } return v; }
+__device__ __forceinline__ uint32_t bvh_wave_max(uint32_t v) { for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o > v ? o : v; } return v; }
+__device__ __forceinline__ int bvh_wave_max_i(int v) { for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o > v ? o : v; } return v; }
+// what one lane wrote (LDS or global) is read by another lane of the same wave after this
+__device__ __forceinline__ void bvh_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 
-// FindBestSplitPlane + the split decision (BVH.cpp:103-163, 169-177) for the nodes list[0 .. gridDim.x).
-__global__ void crt_bvh_split(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtTri* __restrict__ tris)
+// The sweep (BVH.cpp:131-160) by the first 21 lanes of a wave, one lane per candidate plane: lane = 7 * axis + plane. Growing the bin
+// boxes in sweep order is a min/max over the non-empty bins on that side, so a lane can form its two boxes on its own;
+// `planeCost < bestCost` taken in sequence order keeps the FIRST plane that reaches the minimum = the lexicographic minimum of
+// (cost, lane); a NaN cost (an empty side: 0 x Inf) or one that is not below the initial 1e30 never wins. Bins: cnt[3][8],
+// bmin/bmax[3][8][3] as ordered images, in LDS or global memory. All 64 lanes must call; the results are wave-uniform.
+__device__ __forceinline__ void bvh_sweep_lanes(const uint32_t* cnt, const uint32_t* bmin, const uint32_t* bmax, const float* cmin, const float* cmax, uint32_t lane,
+                                                int& axis, float& splitPos, float& bestCost)
 {
-    CrtBuildNode& node = nodes[list[blockIdx.x]];
-    __shared__ uint32_t s_cmin[3], s_cmax[3];
-    __shared__ uint32_t s_cnt[3][CRT_BVH_BINS];
-    __shared__ uint32_t s_bmin[3][CRT_BVH_BINS][3], s_bmax[3][CRT_BVH_BINS][3];
-    const uint32_t first = node.first, n = node.count;
-    for (int k = threadIdx.x; k < 3 * CRT_BVH_BINS; k += blockDim.x) {
-        const int a = k / CRT_BVH_BINS, b = k % CRT_BVH_BINS;
-        s_cnt[a][b] = 0;
-        for (int c = 0; c < 3; ++c) { s_bmin[a][b][c] = bvh_ordered(1e30f); s_bmax[a][b][c] = bvh_ordered(-1e30f); }
-    }
-    if (threadIdx.x < 3) { s_cmin[threadIdx.x] = bvh_ordered(1e30f); s_cmax[threadIdx.x] = bvh_ordered(-1e30f); }
-    __syncthreads();
-    {
-        float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { const float v = bvh_centroid(tris, (size_t)first + i, a); mn[a] = mn[a] < v ? mn[a] : v; mx[a] = mx[a] > v ? mx[a] : v; }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(&s_cmin[a], bvh_ordered(mn[a])); atomicMax(&s_cmax[a], bvh_ordered(mx[a])); }
-    }
-    __syncthreads();
-    float cmin[3], cmax[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { cmin[a] = bvh_unordered(s_cmin[a]); cmax[a] = bvh_unordered(s_cmax[a]); }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float* t = bvh_tri_f(tris, (size_t)first + i);
-        float tmn[3], tmx[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float lo = 1e30f, hi = -1e30f;
-#pragma unroll
-            for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; lo = lo < x ? lo : x; hi = hi > x ? hi : x; }
-            tmn[c] = lo; tmx[c] = hi;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (cmax[a] == cmin[a]) continue;
-            const float scale = (float)CRT_BVH_BINS / (cmax[a] - cmin[a]);
-            int b = f2i((t[3 + 4 * a] - cmin[a]) * scale);
-            b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
-            if (b < 0) b = 0;
-            atomicAdd(&s_cnt[a][b], 1u);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { atomicMin(&s_bmin[a][b][c], bvh_ordered(tmn[c])); atomicMax(&s_bmax[a][b][c], bvh_ordered(tmx[c])); }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    // the sweep, literally (BVH.cpp:131-160)
-    float bestCost = 1e30f, splitPos = 0.0f; int bestAxis = 0;
-    for (int a = 0; a < 3; ++a) {
-        if (cmax[a] == cmin[a]) continue;
-        float leftArea[CRT_BVH_BINS - 1], rightArea[CRT_BVH_BINS - 1];
-        int leftCount[CRT_BVH_BINS - 1], rightCount[CRT_BVH_BINS - 1];
-        int leftSum = 0, rightSum = 0;
-        float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
-        float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
-        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
-            leftSum += (int)s_cnt[a][i];
-            leftCount[i] = leftSum;
-            {   // aabb::grow(aabb) (BVH.cpp:29-37): skipped for an empty box
+    float cost = 1e30f, myPos = 0.0f; uint32_t idx = 64u + lane;
+    if (lane < 3 * (CRT_BVH_BINS - 1)) {
+        const int a = (int)lane / (CRT_BVH_BINS - 1), p = (int)lane % (CRT_BVH_BINS - 1);
+        const float lo = a == 0 ? cmin[0] : (a == 1 ? cmin[1] : cmin[2]), hi = a == 0 ? cmax[0] : (a == 1 ? cmax[1] : cmax[2]);
+        if (!(hi == lo)) {
+            int leftSum = 0, rightSum = 0;
+            float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
+            float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
+            for (int i = 0; i < CRT_BVH_BINS; ++i) {
+                const int c_ = (int)cnt[a * CRT_BVH_BINS + i];
                 float bmn[3], bmx[3];
-                for (int c = 0; c < 3; ++c) { bmn[c] = bvh_unordered(s_bmin[a][i][c]); bmx[c] = bvh_unordered(s_bmax[a][i][c]); }
-                if (bmn[0] != 1e30f)
-                    for (int c = 0; c < 3; ++c) {
-                        lmn[c] = lmn[c] < bmn[c] ? lmn[c] : bmn[c]; lmx[c] = lmx[c] > bmn[c] ? lmx[c] : bmn[c];
-                        lmn[c] = lmn[c] < bmx[c] ? lmn[c] : bmx[c]; lmx[c] = lmx[c] > bmx[c] ? lmx[c] : bmx[c];
-                    }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { bmn[c] = bvh_unordered(bmin[(a * CRT_BVH_BINS + i) * 3 + c]); bmx[c] = bvh_unordered(bmax[(a * CRT_BVH_BINS + i) * 3 + c]); }
+                const bool grow = bmn[0] != 1e30f;           // aabb::grow(aabb) (BVH.cpp:29-37): skipped for an empty box
+                if (i <= p) {
+                    leftSum += c_;
+                    if (grow)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            lmn[c] = lmn[c] < bmn[c] ? lmn[c] : bmn[c]; lmx[c] = lmx[c] > bmn[c] ? lmx[c] : bmn[c];
+                            lmn[c] = lmn[c] < bmx[c] ? lmn[c] : bmx[c]; lmx[c] = lmx[c] > bmx[c] ? lmx[c] : bmx[c];
+                        }
+                } else {
+                    rightSum += c_;
+                    if (grow)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            rmn[c] = rmn[c] < bmn[c] ? rmn[c] : bmn[c]; rmx[c] = rmx[c] > bmn[c] ? rmx[c] : bmn[c];
+                            rmn[c] = rmn[c] < bmx[c] ? rmn[c] : bmx[c]; rmx[c] = rmx[c] > bmx[c] ? rmx[c] : bmx[c];
+                        }
+                }
             }
-            leftArea[i] = bvh_area(lmn, lmx);
-            const int rb = CRT_BVH_BINS - 1 - i;
-            rightSum += (int)s_cnt[a][rb];
-            rightCount[CRT_BVH_BINS - 2 - i] = rightSum;
-            {
-                float bmn[3], bmx[3];
-                for (int c = 0; c < 3; ++c) { bmn[c] = bvh_unordered(s_bmin[a][rb][c]); bmx[c] = bvh_unordered(s_bmax[a][rb][c]); }
-                if (bmn[0] != 1e30f)
-                    for (int c = 0; c < 3; ++c) {
-                        rmn[c] = rmn[c] < bmn[c] ? rmn[c] : bmn[c]; rmx[c] = rmx[c] > bmn[c] ? rmx[c] : bmn[c];
-                        rmn[c] = rmn[c] < bmx[c] ? rmn[c] : bmx[c]; rmx[c] = rmx[c] > bmx[c] ? rmx[c] : bmx[c];
-                    }
-            }
-            rightArea[CRT_BVH_BINS - 2 - i] = bvh_area(rmn, rmx);
-        }
-        const float scale = (cmax[a] - cmin[a]) / (float)CRT_BVH_BINS;
-        for (int i = 0; i < CRT_BVH_BINS - 1; ++i) {
-            const float planeCost = (float)leftCount[i] * leftArea[i] + (float)rightCount[i] * rightArea[i];
-            if (planeCost < bestCost) { splitPos = cmin[a] + scale * (float)(i + 1); bestAxis = a; bestCost = planeCost; }
+            const float planeCost = (float)leftSum * bvh_area(lmn, lmx) + (float)rightSum * bvh_area(rmn, rmx);
+            const float scale = (hi - lo) / (float)CRT_BVH_BINS;
+            myPos = lo + scale * (float)(p + 1);
+            if (planeCost < 1e30f) { cost = planeCost; idx = lane; }
         }
     }
-    const float nosplitCost = (float)n * bvh_area(node.bmin, node.bmax);
-    node.axis = bestAxis; node.splitPos = splitPos;
-    node.state = (bestCost >= nosplitCost) ? 2u : 1u;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(cost, off, 64); const uint32_t oi = (uint32_t)__shfl_xor((int)idx, off, 64);
+        if (oc < cost || (oc == cost && oi < idx)) { cost = oc; idx = oi; }
+    }
+    const bool found = idx < 3u * (CRT_BVH_BINS - 1);
+    splitPos = found ? __shfl(myPos, (int)(found ? idx : 0u), 64) : 0.0f;
+    axis = found ? (int)idx / (CRT_BVH_BINS - 1) : 0;
+    bestCost = found ? cost : 1e30f;
 }
 
 // block-wide exclusive scan of one flag per thread; returns this thread's rank and the block total
@@ -286,54 +189,294 @@ __device__ __forceinline__ void bvh_copy_tri(CrtTri* __restrict__ dst, size_t d,
     b[0] = q0; b[1] = q1; b[2] = q2; b[3] = q3; b[4] = q4;
 }
 
-// The partition (BVH.cpp:185-195) of the nodes list[0 .. gridDim.x): src -> dst in the closed form above, children appended
-// to the node array and to next level's lists. `rank`, `holes`, `backL` are per-triangle scratch arrays indexed like the
-// triangle pool. A node that stops here ends with the same triangle order in both buffers.
-__global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
-                                  uint32_t poolFirst, uint32_t* __restrict__ rank, uint32_t* __restrict__ holes, uint32_t* __restrict__ backL,
-                                  uint32_t levelEnd, unsigned long long* __restrict__ packed, CrtBuildLists next)
+// ---- BIG nodes (> CRT_BVH_SMALL triangles): CRT_BVH_CHUNK triangles per workgroup, as many workgroups as the level's BIG nodes need ----
+// One workgroup per node (r2) left the top of the tree on 8-128 CUs: 4.9 of the 11.6 ms of a 1 M-triangle build went into the first
+// eight levels. Here a level's BIG nodes are cut into chunks of CRT_BVH_CHUNK triangles; `chunkNode[c]` names the node (its slot in the
+// level's BIG list) chunk c belongs to, and CrtBigScratch[slot] holds what the node's chunks reduce into with global atomics (bounds,
+// centroid range, bins) or agree on (L, G). The closed-form partition needs ordered ranks across chunks: per-chunk counts, which every
+// chunk sums for itself over its node's chunks (a node has at most a thousand), then ranks inside the chunk by a workgroup scan.
+#define CRT_BVH_CHUNK 1024
+#define CRT_BVH_BIG_THREADS 256
+struct CrtBigScratch {
+    uint32_t bmin[3], bmax[3];        // vertex bounds, ordered images
+    uint32_t cmin[3], cmax[3];        // centroid range
+    int last[6];                      // last zero in sequence order per bound (3 * triangle + vertex), -1 = none
+    uint32_t chunkBase, nChunks;      // this node's chunks: chunkBase .. chunkBase + nChunks
+    uint32_t L, G;
+    uint32_t cnt[3 * CRT_BVH_BINS];
+    uint32_t bbmin[3 * CRT_BVH_BINS * 3], bbmax[3 * CRT_BVH_BINS * 3];
+};
+struct CrtBuildCtl { unsigned long long packed; uint32_t nextChunks; uint32_t degenerate; };   // read back by the host after every level
+__host__ __device__ __forceinline__ uint32_t bvh_chunks(uint32_t n) { return (n + CRT_BVH_CHUNK - 1) / CRT_BVH_CHUNK; }
+
+// sum over the workgroup; every thread gets the total. s_red: one word per wave
+__device__ __forceinline__ uint32_t bvh_block_sum(uint32_t v, uint32_t* s_red)
 {
-    CrtBuildNode& node = nodes[list[blockIdx.x]];
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_L;
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+    const uint32_t nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (uint32_t w = 0; w < nw; ++w) t += s_red[w];
+    __syncthreads();
+    return t;
+}
+
+// level 0: the roots; BIG ones get their slot (mesh order, as the host fills the BIG list) and their chunks
+__global__ void crt_bvh_init_roots(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ meshTriCounts, int numMeshes, uint32_t firstTri,
+                                   CrtBigScratch* __restrict__ big, uint32_t* __restrict__ chunkNode)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t cur = firstTri, slot = 0, chunk = 0;
+    for (int m = 0; m < numMeshes; ++m) {
+        CrtBuildNode n;
+        n.first = cur; n.count = meshTriCounts[m]; n.left = n.right = CRT_BVH_NONE;
+        for (int c = 0; c < 3; ++c) { n.bmin[c] = 1e30f; n.bmax[c] = -1e30f; }
+        n.splitPos = 0.0f; n.axis = 0; n.state = 0; n.desc = 0; n.index = 0; n.base = 0; n.pad = 0;
+        nodes[m] = n;
+        cur += meshTriCounts[m];
+        if (bvh_class(n.count) == CRT_BVH_CLASS_BIG) {
+            const uint32_t nch = bvh_chunks(n.count);
+            big[slot].chunkBase = chunk; big[slot].nChunks = nch;
+            for (uint32_t c = 0; c < nch; ++c) chunkNode[chunk + c] = slot;
+            chunk += nch; ++slot;
+        }
+    }
+}
+
+__global__ void crt_bvh_big_reset(CrtBigScratch* __restrict__ big, uint32_t count)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    CrtBigScratch& B = big[k];
+    for (int c = 0; c < 3; ++c) { B.bmin[c] = B.cmin[c] = bvh_ordered(1e30f); B.bmax[c] = B.cmax[c] = bvh_ordered(-1e30f); }
+    for (int c = 0; c < 6; ++c) B.last[c] = -1;
+    B.L = 0; B.G = 0;
+    for (int j = 0; j < 3 * CRT_BVH_BINS; ++j) B.cnt[j] = 0;
+    for (int j = 0; j < 9 * CRT_BVH_BINS; ++j) { B.bbmin[j] = bvh_ordered(1e30f); B.bbmax[j] = bvh_ordered(-1e30f); }
+}
+
+// UpdateNodeBounds (BVH.cpp:54-74) + the centroid range of FindBestSplitPlane (BVH.cpp:108-113): min/max reductions, order-free.
+__global__ void __launch_bounds__(CRT_BVH_BIG_THREADS) crt_bvh_big_bounds(const CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, CrtBigScratch* __restrict__ big,
+                                                                          const uint32_t* __restrict__ chunkNode, const CrtTri* __restrict__ tris)
+{
+    const uint32_t k = chunkNode[blockIdx.x];
+    CrtBigScratch& B = big[k];
+    const CrtBuildNode& node = nodes[list[k]];
     const uint32_t first = node.first, n = node.count;
-    if (node.state != 1u) {                                   // leaf by the cost test: same order in both buffers
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) bvh_copy_tri(dst, (size_t)first + i, src, (size_t)first + i);
+    const uint32_t lo = (blockIdx.x - B.chunkBase) * CRT_BVH_CHUNK, hi = (lo + CRT_BVH_CHUNK) < n ? (lo + CRT_BVH_CHUNK) : n;
+    float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
+    float cn[3] = { 1e30f, 1e30f, 1e30f }, cx[3] = { -1e30f, -1e30f, -1e30f };
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float* t = bvh_tri_f(tris, (size_t)first + i);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; mn[c] = mn[c] < x ? mn[c] : x; mx[c] = mx[c] > x ? mx[c] : x; }
+            const float ce = t[3 + 4 * c]; cn[c] = cn[c] < ce ? cn[c] : ce; cx[c] = cx[c] > ce ? cx[c] : ce;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t a = bvh_wave_min(bvh_ordered(mn[c])), b = bvh_wave_max(bvh_ordered(mx[c]));
+        const uint32_t d = bvh_wave_min(bvh_ordered(cn[c])), e = bvh_wave_max(bvh_ordered(cx[c]));
+        if ((threadIdx.x & 63) == 0) { atomicMin(&B.bmin[c], a); atomicMax(&B.bmax[c], b); atomicMin(&B.cmin[c], d); atomicMax(&B.cmax[c], e); }
+    }
+}
+
+// The bins of FindBestSplitPlane (BVH.cpp:115-129): per workgroup in LDS, then one global atomic per non-empty bin word. Also the
+// look-up behind the sign of a zero bound (see crt_bvh_bounds_wave), which needs the finished bounds and reads the same triangles.
+__global__ void __launch_bounds__(CRT_BVH_BIG_THREADS) crt_bvh_big_bins(const CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, CrtBigScratch* __restrict__ big,
+                                                                        const uint32_t* __restrict__ chunkNode, const CrtTri* __restrict__ tris)
+{
+    __shared__ uint32_t s_cnt[3 * CRT_BVH_BINS];
+    __shared__ uint32_t s_bmin[9 * CRT_BVH_BINS], s_bmax[9 * CRT_BVH_BINS];
+    const uint32_t k = chunkNode[blockIdx.x];
+    CrtBigScratch& B = big[k];
+    const CrtBuildNode& node = nodes[list[k]];
+    const uint32_t first = node.first, n = node.count;
+    const uint32_t lo = (blockIdx.x - B.chunkBase) * CRT_BVH_CHUNK, hi = (lo + CRT_BVH_CHUNK) < n ? (lo + CRT_BVH_CHUNK) : n;
+    for (int j = threadIdx.x; j < 3 * CRT_BVH_BINS; j += blockDim.x) s_cnt[j] = 0;
+    for (int j = threadIdx.x; j < 9 * CRT_BVH_BINS; j += blockDim.x) { s_bmin[j] = bvh_ordered(1e30f); s_bmax[j] = bvh_ordered(-1e30f); }
+    float cmin[3], cmax[3], rmin[3], rmax[3];
+    bool anyZero = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        cmin[a] = bvh_unordered(B.cmin[a]); cmax[a] = bvh_unordered(B.cmax[a]);
+        rmin[a] = bvh_unordered(B.bmin[a]); rmax[a] = bvh_unordered(B.bmax[a]);
+        anyZero = anyZero || rmin[a] == 0.0f || rmax[a] == 0.0f;
+    }
+    __syncthreads();
+    int last[6] = { -1, -1, -1, -1, -1, -1 };
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float* t = bvh_tri_f(tris, (size_t)first + i);
+        float tmn[3], tmx[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float l = 1e30f, h = -1e30f;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float x = t[4 * v + c]; l = l < x ? l : x; h = h > x ? h : x;
+                if (anyZero && x == 0.0f) {
+                    const int s = (int)(i * 3 + v);
+                    if (rmin[c] == 0.0f) last[c] = last[c] > s ? last[c] : s;
+                    if (rmax[c] == 0.0f) last[3 + c] = last[3 + c] > s ? last[3 + c] : s;
+                }
+            }
+            tmn[c] = l; tmx[c] = h;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (cmax[a] == cmin[a]) continue;
+            const float scale = (float)CRT_BVH_BINS / (cmax[a] - cmin[a]);
+            int b = f2i((t[3 + 4 * a] - cmin[a]) * scale);
+            b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
+            if (b < 0) b = 0;
+            atomicAdd(&s_cnt[a * CRT_BVH_BINS + b], 1u);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { atomicMin(&s_bmin[(a * CRT_BVH_BINS + b) * 3 + c], bvh_ordered(tmn[c])); atomicMax(&s_bmax[(a * CRT_BVH_BINS + b) * 3 + c], bvh_ordered(tmx[c])); }
+        }
+    }
+    if (anyZero)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { const int m = bvh_wave_max_i(last[c]); if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(&B.last[c], m); }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 3 * CRT_BVH_BINS; j += blockDim.x) {
+        if (s_cnt[j] == 0) continue;
+        atomicAdd(&B.cnt[j], s_cnt[j]);
+        for (int c = 0; c < 3; ++c) { atomicMin(&B.bbmin[j * 3 + c], s_bmin[j * 3 + c]); atomicMax(&B.bbmax[j * 3 + c], s_bmax[j * 3 + c]); }
+    }
+}
+
+// The sweep and the split decision (BVH.cpp:131-163, 169-177), replayed by every chunk of the node for itself (the node's first chunk
+// stores them), then the chunk's share of L = the number of left-class triangles. A node that stays a leaf by the cost test is
+// copied to the other buffer here, in the same order.
+__global__ void __launch_bounds__(CRT_BVH_BIG_THREADS) crt_bvh_big_sweep(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtBigScratch* __restrict__ big,
+                                                                         const uint32_t* __restrict__ chunkNode, const CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
+                                                                         uint32_t* __restrict__ chunkL)
+{
+    __shared__ uint32_t s_red[CRT_BVH_BIG_THREADS / 64];
+    const uint32_t k = chunkNode[blockIdx.x];
+    const CrtBigScratch& B = big[k];
+    CrtBuildNode& node = nodes[list[k]];
+    const uint32_t first = node.first, n = node.count;
+    const uint32_t chunk = blockIdx.x - B.chunkBase;
+    const uint32_t lo = chunk * CRT_BVH_CHUNK, hi = (lo + CRT_BVH_CHUNK) < n ? (lo + CRT_BVH_CHUNK) : n;
+    float cmin[3], cmax[3], rmin[3], rmax[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        cmin[c] = bvh_unordered(B.cmin[c]); cmax[c] = bvh_unordered(B.cmax[c]);
+        rmin[c] = bvh_unordered(B.bmin[c]); rmax[c] = bvh_unordered(B.bmax[c]);
+        if (rmin[c] == 0.0f && B.last[c] >= 0) rmin[c] = bvh_tri_f(src, (size_t)first + B.last[c] / 3)[4 * (B.last[c] % 3) + c];
+        if (rmax[c] == 0.0f && B.last[3 + c] >= 0) rmax[c] = bvh_tri_f(src, (size_t)first + B.last[3 + c] / 3)[4 * (B.last[3 + c] % 3) + c];
+    }
+    int axis; float splitPos, bestCost;                        // every wave replays the sweep: no broadcast needed
+    bvh_sweep_lanes(B.cnt, B.bbmin, B.bbmax, cmin, cmax, threadIdx.x & 63, axis, splitPos, bestCost);
+    const float nosplitCost = (float)n * bvh_area(rmin, rmax);
+    const bool isLeaf = bestCost >= nosplitCost;
+    if (chunk == 0 && threadIdx.x == 0) {
+        for (int c = 0; c < 3; ++c) { node.bmin[c] = rmin[c]; node.bmax[c] = rmax[c]; }
+        node.axis = axis; node.splitPos = splitPos; node.state = isLeaf ? 2u : 1u;
+    }
+    if (isLeaf) {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) bvh_copy_tri(dst, (size_t)first + i, src, (size_t)first + i);
         return;
     }
+    uint32_t c = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) c += bvh_centroid(src, (size_t)first + i, axis) < splitPos ? 1u : 0u;
+    c = bvh_block_sum(c, s_red);
+    if (threadIdx.x == 0) chunkL[blockIdx.x] = c;
+}
+
+// L, then the chunk's number of right-class triangles below L (the holes) and of left-class triangles at or above L.
+__global__ void __launch_bounds__(CRT_BVH_BIG_THREADS) crt_bvh_big_count(const CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, CrtBigScratch* __restrict__ big,
+                                                                         const uint32_t* __restrict__ chunkNode, const CrtTri* __restrict__ src, const uint32_t* __restrict__ chunkL,
+                                                                         uint32_t* __restrict__ chunkFR, uint32_t* __restrict__ chunkBL)
+{
+    __shared__ uint32_t s_red[CRT_BVH_BIG_THREADS / 64];
+    const uint32_t k = chunkNode[blockIdx.x];
+    CrtBigScratch& B = big[k];
+    const CrtBuildNode& node = nodes[list[k]];
+    if (node.state != 1u) return;
+    const uint32_t first = node.first, n = node.count;
+    const uint32_t chunk = blockIdx.x - B.chunkBase;
+    const uint32_t lo = chunk * CRT_BVH_CHUNK, hi = (lo + CRT_BVH_CHUNK) < n ? (lo + CRT_BVH_CHUNK) : n;
+    const int axis = node.axis; const float splitPos = node.splitPos;
+    uint32_t l = 0;
+    for (uint32_t j = threadIdx.x; j < B.nChunks; j += blockDim.x) l += chunkL[B.chunkBase + j];
+    const uint32_t L = bvh_block_sum(l, s_red);
+    uint32_t fr = 0, bl = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const bool isLeft = bvh_centroid(src, (size_t)first + i, axis) < splitPos;
+        fr += (i < L && !isLeft) ? 1u : 0u; bl += (i >= L && isLeft) ? 1u : 0u;
+    }
+    fr = bvh_block_sum(fr, s_red); bl = bvh_block_sum(bl, s_red);
+    if (threadIdx.x == 0) { chunkFR[blockIdx.x] = fr; chunkBL[blockIdx.x] = bl; if (chunk == 0) B.L = L; }
+}
+
+// The tables of the closed form (see the header): rank of every right-class element of the front region among the holes and
+// holes[m] = x; rank of every left-class element of the back region in back order (y = n-1-x) and backL[m] = y.
+__global__ void __launch_bounds__(CRT_BVH_BIG_THREADS) crt_bvh_big_tables(const CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, CrtBigScratch* __restrict__ big,
+                                                                          const uint32_t* __restrict__ chunkNode, const CrtTri* __restrict__ src, uint32_t poolFirst,
+                                                                          const uint32_t* __restrict__ chunkFR, const uint32_t* __restrict__ chunkBL,
+                                                                          uint32_t* __restrict__ rank, uint32_t* __restrict__ holes, uint32_t* __restrict__ backL)
+{
+    __shared__ uint32_t s_red[CRT_BVH_BIG_THREADS / 64];
+    __shared__ uint32_t s_wave[16];
+    const uint32_t k = chunkNode[blockIdx.x];
+    CrtBigScratch& B = big[k];
+    const CrtBuildNode& node = nodes[list[k]];
+    if (node.state != 1u) return;
+    const uint32_t first = node.first, n = node.count, L = B.L;
+    const uint32_t chunk = blockIdx.x - B.chunkBase;
+    const uint32_t lo = chunk * CRT_BVH_CHUNK, hi = (lo + CRT_BVH_CHUNK) < n ? (lo + CRT_BVH_CHUNK) : n;
     const int axis = node.axis; const float splitPos = node.splitPos;
     uint32_t* rk = rank + (first - poolFirst); uint32_t* hl = holes + (first - poolFirst); uint32_t* bl = backL + (first - poolFirst);
-    if (threadIdx.x == 0) s_L = 0;
-    __syncthreads();
-    {
-        uint32_t c = 0;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) c += bvh_centroid(src, (size_t)first + i, axis) < splitPos ? 1u : 0u;
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_L, c);
+    uint32_t gb = 0, ga = 0, bb = 0;                           // holes in earlier chunks / in all chunks; back-order left-class elements in later chunks
+    for (uint32_t j = threadIdx.x; j < B.nChunks; j += blockDim.x) {
+        const uint32_t f = chunkFR[B.chunkBase + j];
+        ga += f; if (j < chunk) gb += f;
+        if (j > chunk) bb += chunkBL[B.chunkBase + j];
     }
-    __syncthreads();
-    const uint32_t L = s_L;
-    // front region [0, L): rank of every right-class element among the holes, holes[m] = x
-    uint32_t G = 0;
-    for (uint32_t base = 0; base < L; base += blockDim.x) {
+    uint32_t G = bvh_block_sum(gb, s_red); const uint32_t Gall = bvh_block_sum(ga, s_red); uint32_t GB = bvh_block_sum(bb, s_red);
+    if (chunk == 0 && threadIdx.x == 0) B.G = Gall;
+    for (uint32_t base = lo; base < hi; base += blockDim.x) {
         const uint32_t x = base + threadIdx.x;
-        const bool isR = x < L && !(bvh_centroid(src, (size_t)first + x, axis) < splitPos);
+        const bool isR = x < hi && x < L && !(bvh_centroid(src, (size_t)first + x, axis) < splitPos);
         uint32_t tot; const uint32_t r = bvh_block_scan(isR ? 1u : 0u, s_wave, tot);
         if (isR) { rk[x] = G + r; hl[G + r] = x; }
         G += tot;
     }
-    // back region in back order y = n-1-x, x >= L: rank of every left-class element, backL[m] = y
-    uint32_t GB = 0;
-    const uint32_t nb = n - L;
-    for (uint32_t base = 0; base < nb; base += blockDim.x) {
-        const uint32_t y = base + threadIdx.x;
-        const bool isL = y < nb && (bvh_centroid(src, (size_t)first + (n - 1 - y), axis) < splitPos);
+    for (uint32_t base = 0; base < hi - lo; base += blockDim.x) {   // back order: x descending
+        const uint32_t o = base + threadIdx.x;
+        const uint32_t x = hi - 1 - o;                               // only meaningful while o < hi - lo
+        const bool isL = o < hi - lo && x >= L && (bvh_centroid(src, (size_t)first + x, axis) < splitPos);
         uint32_t tot; const uint32_t r = bvh_block_scan(isL ? 1u : 0u, s_wave, tot);
-        if (isL) { rk[n - 1 - y] = GB + r; bl[GB + r] = y; }
+        if (isL) { rk[x] = GB + r; bl[GB + r] = n - 1 - x; }
         GB += tot;
     }
-    __syncthreads();                                          // tables complete (G == GB by counting)
-    for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) {
+}
+
+// The move itself (closed form), then -- by the node's first chunk -- the children: two node records, their list slots, and for a BIG
+// child its chunks. A partition that left one side empty (BVH.cpp:194) is only flagged here (state 3): its triangles are copied
+// back by crt_bvh_big_degenerate, which the host launches when the level's control word says there was one.
+__global__ void __launch_bounds__(CRT_BVH_BIG_THREADS) crt_bvh_big_scatter(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtBigScratch* __restrict__ big,
+                                                                           const uint32_t* __restrict__ chunkNode, const CrtTri* __restrict__ src, CrtTri* __restrict__ dst, uint32_t poolFirst,
+                                                                           const uint32_t* __restrict__ rank, const uint32_t* __restrict__ holes, const uint32_t* __restrict__ backL,
+                                                                           uint32_t levelEnd, CrtBuildCtl* __restrict__ ctl, CrtBuildLists next,
+                                                                           CrtBigScratch* __restrict__ nextBig, uint32_t* __restrict__ nextChunkNode)
+{
+    __shared__ uint32_t s_fill[2][3];                          // per BIG child: slot, chunkBase, nChunks
+    const uint32_t k = chunkNode[blockIdx.x];
+    const CrtBigScratch& B = big[k];
+    CrtBuildNode& node = nodes[list[k]];
+    if (node.state != 1u) return;
+    const uint32_t first = node.first, n = node.count, L = B.L, G = B.G;
+    const uint32_t chunk = blockIdx.x - B.chunkBase;
+    const uint32_t lo = chunk * CRT_BVH_CHUNK, hi = (lo + CRT_BVH_CHUNK) < n ? (lo + CRT_BVH_CHUNK) : n;
+    const int axis = node.axis; const float splitPos = node.splitPos;
+    const uint32_t* rk = rank + (first - poolFirst); const uint32_t* hl = holes + (first - poolFirst); const uint32_t* bl = backL + (first - poolFirst);
+    for (uint32_t x = lo + threadIdx.x; x < hi; x += blockDim.x) {
         const bool isLeft = bvh_centroid(src, (size_t)first + x, axis) < splitPos;
         uint32_t dest;
         if (x < L) {
@@ -344,14 +487,50 @@ __global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, const uint32
         else dest = x - 1;
         bvh_copy_tri(dst, (size_t)first + dest, src, (size_t)first + x);
     }
-    if (L == 0 || L == n) {                                   // BVH.cpp:194: stays a leaf, triangles stay permuted -> both buffers
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) bvh_copy_tri(src, (size_t)first + i, dst, (size_t)first + i);
-        if (threadIdx.x == 0) node.state = 3u;
-    } else if (threadIdx.x == 0) {
-        const unsigned long long before = atomicAdd(packed, bvh_pack_one(bvh_class(L)) + bvh_pack_one(bvh_class(n - L)));
-        bvh_new_children(nodes, node, first, L, n, levelEnd, before, next);
+    if (chunk != 0) return;
+    if (L == 0 || L == n) {
+        if (threadIdx.x == 0) { atomicAdd(&ctl->degenerate, 1u); }
+        return;                                                // node.state is set by crt_bvh_big_degenerate (other chunks still read it here)
     }
+    if (threadIdx.x == 0) {
+        const int cl = bvh_class(L), cr = bvh_class(n - L);
+        const unsigned long long before = atomicAdd(&ctl->packed, bvh_pack_one(cl) + bvh_pack_one(cr));
+        bvh_new_children(nodes, node, first, L, n, levelEnd, before, next);
+        const uint32_t slot[2] = { bvh_unpack(before, cl), bvh_unpack(before + bvh_pack_one(cl), cr) };
+        const uint32_t cnt[2] = { L, n - L }; const int cls[2] = { cl, cr };
+        for (int j = 0; j < 2; ++j) {
+            s_fill[j][2] = 0;
+            if (cls[j] != CRT_BVH_CLASS_BIG) continue;
+            const uint32_t nch = bvh_chunks(cnt[j]);
+            const uint32_t base = atomicAdd(&ctl->nextChunks, nch);
+            nextBig[slot[j]].chunkBase = base; nextBig[slot[j]].nChunks = nch;
+            s_fill[j][0] = slot[j]; s_fill[j][1] = base; s_fill[j][2] = nch;
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < 2; ++j)
+        for (uint32_t c = threadIdx.x; c < s_fill[j][2]; c += blockDim.x) nextChunkNode[s_fill[j][1] + c] = s_fill[j][0];
+}
+
+// BVH.cpp:194 for BIG nodes: the node stays a leaf, its triangles stay permuted -> the partition's output goes to both buffers
+__global__ void __launch_bounds__(CRT_BVH_BIG_THREADS) crt_bvh_big_degenerate(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtBigScratch* __restrict__ big,
+                                                                              const uint32_t* __restrict__ chunkNode, CrtTri* __restrict__ src, const CrtTri* __restrict__ dst)
+{
+    const uint32_t k = chunkNode[blockIdx.x];
+    const CrtBigScratch& B = big[k];
+    CrtBuildNode& node = nodes[list[k]];
+    const uint32_t first = node.first, n = node.count;
+    if (node.left != CRT_BVH_NONE || (node.state != 1u && node.state != 3u) || !(B.L == 0 || B.L == n)) return;
+    const uint32_t chunk = blockIdx.x - B.chunkBase;
+    const uint32_t lo = chunk * CRT_BVH_CHUNK, hi = (lo + CRT_BVH_CHUNK) < n ? (lo + CRT_BVH_CHUNK) : n;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) bvh_copy_tri(src, (size_t)first + i, dst, (size_t)first + i);
+}
+__global__ void crt_bvh_big_degenerate_mark(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, const CrtBigScratch* __restrict__ big, uint32_t count)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    CrtBuildNode& node = nodes[list[k]];
+    if (node.left == CRT_BVH_NONE && node.state == 1u && (big[k].L == 0 || big[k].L == node.count)) node.state = 3u;
 }
 
 // ---- MID nodes (9 .. CRT_BVH_SMALL triangles), one WAVE per node and CRT_BVH_WAVES nodes per workgroup ----
@@ -361,13 +540,7 @@ __global__ void crt_bvh_partition(CrtBuildNode* __restrict__ nodes, const uint32
 // 21 candidate planes are evaluated by 21 lanes instead of one thread, and the workgroup's waves share ONE atomic.
 #define CRT_BVH_WAVES 8
 #define CRT_BVH_LDS_TABLE 128         // partition tables of nodes up to this size live in LDS, larger ones in the global scratch
-__device__ __forceinline__ uint32_t bvh_wave_min(uint32_t v) { for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o < v ? o : v; } return v; }
-__device__ __forceinline__ uint32_t bvh_wave_max(uint32_t v) { for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o > v ? o : v; } return v; }
-__device__ __forceinline__ int bvh_wave_max_i(int v) { for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o > v ? o : v; } return v; }
-// what one lane wrote (LDS or global) is read by another lane of the same wave after this
-__device__ __forceinline__ void bvh_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-
-// UpdateNodeBounds (BVH.cpp:54-74) for the nodes list[0 .. count): same reductions as crt_bvh_bounds, per wave.
+// UpdateNodeBounds (BVH.cpp:54-74) for the nodes list[0 .. count): min/max reductions per wave.
 __global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_bounds_wave(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, const CrtTri* __restrict__ tris)
 {
     const uint32_t k = blockIdx.x * CRT_BVH_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -388,7 +561,8 @@ __global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_bounds_wave(CrtBui
     bool anyZero = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) anyZero = anyZero || rmin[c] == 0.0f || rmax[c] == 0.0f;
-    if (anyZero) {                                            // the sign of a zero bound: the last zero in sequence order (see crt_bvh_bounds)
+    // sign of a zero bound: the sequential fold `acc < x ? acc : x` keeps the LAST zero it meets (tris in order, v0 v1 v2)
+    if (anyZero) {
         int last[6] = { -1, -1, -1, -1, -1, -1 };
         for (uint32_t i = lane; i < n; i += 64) {
             const float* t = bvh_tri_f(tris, (size_t)first + i);
@@ -466,63 +640,15 @@ __global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_mid(CrtBuildNode* 
             }
         }
         bvh_wave_sync();
-        // the sweep (BVH.cpp:131-160), one lane per candidate plane: lane = 7 * axis + plane. Growing the bin boxes in sweep order is a
-        // min/max over the non-empty bins on that side, so a lane can form its two boxes on its own; `planeCost < bestCost` taken in
-        // sequence order keeps the FIRST plane that reaches the minimum = the lexicographic minimum of (cost, lane); a NaN cost (an
-        // empty side: 0 x Inf) or one that is not below the initial 1e30 never wins.
-        float cost = 1e30f, myPos = 0.0f; uint32_t idx = 64u + lane;
-        if (lane < 3 * (CRT_BVH_BINS - 1)) {
-            const int a = (int)lane / (CRT_BVH_BINS - 1), p = (int)lane % (CRT_BVH_BINS - 1);
-            const float lo = a == 0 ? cmin[0] : (a == 1 ? cmin[1] : cmin[2]), hi = a == 0 ? cmax[0] : (a == 1 ? cmax[1] : cmax[2]);
-            if (!(hi == lo)) {
-                int leftSum = 0, rightSum = 0;
-                float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
-                float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
-                for (int i = 0; i < CRT_BVH_BINS; ++i) {
-                    const int c_ = (int)s_cnt[w][a][i];
-                    float bmn[3], bmx[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { bmn[c] = bvh_unordered(s_bmin[w][a][i][c]); bmx[c] = bvh_unordered(s_bmax[w][a][i][c]); }
-                    const bool grow = bmn[0] != 1e30f;       // aabb::grow(aabb) (BVH.cpp:29-37): skipped for an empty box
-                    if (i <= p) {
-                        leftSum += c_;
-                        if (grow)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                lmn[c] = lmn[c] < bmn[c] ? lmn[c] : bmn[c]; lmx[c] = lmx[c] > bmn[c] ? lmx[c] : bmn[c];
-                                lmn[c] = lmn[c] < bmx[c] ? lmn[c] : bmx[c]; lmx[c] = lmx[c] > bmx[c] ? lmx[c] : bmx[c];
-                            }
-                    } else {
-                        rightSum += c_;
-                        if (grow)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                rmn[c] = rmn[c] < bmn[c] ? rmn[c] : bmn[c]; rmx[c] = rmx[c] > bmn[c] ? rmx[c] : bmn[c];
-                                rmn[c] = rmn[c] < bmx[c] ? rmn[c] : bmx[c]; rmx[c] = rmx[c] > bmx[c] ? rmx[c] : bmx[c];
-                            }
-                    }
-                }
-                const float planeCost = (float)leftSum * bvh_area(lmn, lmx) + (float)rightSum * bvh_area(rmn, rmx);
-                const float scale = (hi - lo) / (float)CRT_BVH_BINS;
-                myPos = lo + scale * (float)(p + 1);
-                if (planeCost < 1e30f) { cost = planeCost; idx = lane; }
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float oc = __shfl_xor(cost, off, 64); const uint32_t oi = (uint32_t)__shfl_xor((int)idx, off, 64);
-            if (oc < cost || (oc == cost && oi < idx)) { cost = oc; idx = oi; }
-        }
-        const bool found = idx < 3u * (CRT_BVH_BINS - 1);
-        const float splitPos = found ? __shfl(myPos, (int)(found ? idx : 0u), 64) : 0.0f;
-        const int axis = found ? (int)idx / (CRT_BVH_BINS - 1) : 0;
-        const float bestCost = found ? cost : 1e30f;
+        int axis; float splitPos, bestCost;
+        bvh_sweep_lanes(&s_cnt[w][0][0], &s_bmin[w][0][0][0], &s_bmax[w][0][0][0], cmin, cmax, lane, axis, splitPos, bestCost);
         const float nosplitCost = (float)n * bvh_area(node.bmin, node.bmax);
         const bool isLeaf = bestCost >= nosplitCost;
         if (lane == 0) { node.axis = axis; node.splitPos = splitPos; node.state = isLeaf ? 2u : 1u; }
         if (isLeaf) {                                          // same order in both buffers
             for (uint32_t i = lane; i < n; i += 64) bvh_copy_tri(dst, (size_t)first + i, src, (size_t)first + i);
         } else {
-            // the partition in its closed form (see the header and crt_bvh_partition), ballots instead of workgroup scans
+            // the partition in its closed form (see the header), ballots instead of workgroup scans
             const bool inLds = n <= CRT_BVH_LDS_TABLE;
             uint32_t* rk = inLds ? s_tab[w][0] : rank + (first - poolFirst);
             uint32_t* hl = inLds ? s_tab[w][1] : holes + (first - poolFirst);

@@ -741,15 +741,19 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     RCCHK(sync_all());
 
     // second triangle pool (allocated on first use, indexed like rawTris) and scratch:
-    // build nodes | rank, holes, backL | 2 x 3 id lists | mesh counts, roots | scalars
+    // build nodes | rank, holes, backL | 2 x 3 id lists | 2 x BIG-node scratch | 2 x chunk->node + 3 per-chunk counts | mesh counts, roots | scalars
     if (!g.buildTris) HIPCHK(hipMalloc(&g.buildTris, g.triCap * sizeof(CrtTri)));
     const size_t maxNodes = 2 * total + (size_t)numMeshes;
     const size_t offNodes = 0;
     const size_t offRank = (offNodes + maxNodes * sizeof(CrtBuildNode) + 255) & ~(size_t)255;
     const size_t offLists = (offRank + 3 * total * sizeof(uint32_t) + 255) & ~(size_t)255;
     const size_t listCap = total + (size_t)numMeshes;                              // a level never has more nodes than triangles
-    const size_t offSmall = (offLists + 6 * listCap * sizeof(uint32_t) + 255) & ~(size_t)255;
-    const size_t need = offSmall + (2 * (size_t)numMeshes + 8) * sizeof(uint32_t) + sizeof(unsigned long long);
+    const size_t maxBig = total / CRT_BVH_SMALL + (size_t)numMeshes + 1;           // BIG nodes of one level (each has more than CRT_BVH_SMALL triangles)
+    const size_t maxChunks = total / CRT_BVH_CHUNK + maxBig + 1;                   // sum of ceil(n / CRT_BVH_CHUNK) over them
+    const size_t offBig = (offLists + 6 * listCap * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t offChunks = (offBig + 2 * maxBig * sizeof(CrtBigScratch) + 255) & ~(size_t)255;
+    const size_t offSmall = (offChunks + 5 * maxChunks * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t need = offSmall + (2 * (size_t)numMeshes + 8) * sizeof(uint32_t) + sizeof(CrtBuildCtl) + 16;
     if (need > g.buildBytes) {
         if (g.buildBuf) (void)hipFree(g.buildBuf);
         g.buildBuf = nullptr; g.buildBytes = 0;
@@ -765,17 +769,26 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     uint32_t* listMem = reinterpret_cast<uint32_t*>(base + offLists);
     CrtBuildLists lists[2];
     for (int p = 0; p < 2; ++p) for (int c = 0; c < 3; ++c) lists[p].list[c] = listMem + ((size_t)p * 3 + (size_t)c) * listCap;
+    CrtBigScratch* bigs[2] = { reinterpret_cast<CrtBigScratch*>(base + offBig), reinterpret_cast<CrtBigScratch*>(base + offBig) + maxBig };
+    uint32_t* chunkMem = reinterpret_cast<uint32_t*>(base + offChunks);
+    uint32_t* chunkNode[2] = { chunkMem, chunkMem + maxChunks };
+    uint32_t* chunkL = chunkMem + 2 * maxChunks; uint32_t* chunkFR = chunkL + maxChunks; uint32_t* chunkBL = chunkFR + maxChunks;
     uint32_t* dCounts = reinterpret_cast<uint32_t*>(base + offSmall);
     uint32_t* dRoots = dCounts + numMeshes;
     uint32_t* dScal = dRoots + numMeshes;                                          // [0] nodes used
-    unsigned long long* dPacked = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(dScal + 2) + 7) & ~(uintptr_t)7);   // next level's list sizes (crt_bvh_build.h)
+    CrtBuildCtl* dCtl = reinterpret_cast<CrtBuildCtl*>((reinterpret_cast<uintptr_t>(dScal + 2) + 15) & ~(uintptr_t)15);   // next level's list sizes and chunk count (crt_bvh_build.h)
     hipStream_t st = g.stream;
     HIPCHK(hipMemcpyAsync(dCounts, meshTriCounts, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     // level 0 = the roots, classified here
     uint32_t cnt[3] = { 0, 0, 0 };
+    uint32_t chunks = 0;                                                           // chunks of the current level's BIG nodes
     {
         std::vector<uint32_t> ids[3];
-        for (int m = 0; m < numMeshes; ++m) ids[bvh_class(meshTriCounts[m])].push_back((uint32_t)m);
+        for (int m = 0; m < numMeshes; ++m) {
+            const int cls = bvh_class(meshTriCounts[m]);
+            ids[cls].push_back((uint32_t)m);
+            if (cls == CRT_BVH_CLASS_BIG) chunks += bvh_chunks(meshTriCounts[m]);
+        }
         for (int c = 0; c < 3; ++c) {
             cnt[c] = (uint32_t)ids[c].size();
             if (cnt[c]) HIPCHK(hipMemcpyAsync(lists[0].list[c], ids[c].data(), cnt[c] * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -783,15 +796,18 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         HIPCHK(hipStreamSynchronize(st));                                          // ids[] go out of scope
     }
     crt_bvh_centroids<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(A, firstTri, total);
-    crt_bvh_init_roots<<<1, 1, 0, st>>>(bn, dCounts, numMeshes, (uint32_t)firstTri);
+    crt_bvh_init_roots<<<1, 1, 0, st>>>(bn, dCounts, numMeshes, (uint32_t)firstTri, bigs[0], chunkNode[0]);
     HIPCHK(hipGetLastError());
 
-    auto bounds = [&](const CrtBuildLists& L, const uint32_t n[3], const CrtTri* tris) {
-        if (n[0]) crt_bvh_bounds<<<n[0], 1024, 0, st>>>(bn, L.list[0], tris);
-        if (n[1]) crt_bvh_bounds_wave<<<(n[1] + CRT_BVH_WAVES - 1) / CRT_BVH_WAVES, 64 * CRT_BVH_WAVES, 0, st>>>(bn, L.list[1], n[1], tris);
+    const unsigned W = CRT_BVH_WAVES, T = CRT_BVH_BIG_THREADS;
+    auto bounds = [&](int p, const uint32_t n[3], uint32_t nChunks, const CrtTri* tris) {
+        const CrtBuildLists& L = lists[p];
+        if (n[0]) { crt_bvh_big_reset<<<(n[0] + 255) / 256, 256, 0, st>>>(bigs[p], n[0]);
+                    crt_bvh_big_bounds<<<nChunks, T, 0, st>>>(bn, L.list[0], bigs[p], chunkNode[p], tris); }
+        if (n[1]) crt_bvh_bounds_wave<<<(n[1] + W - 1) / W, 64 * W, 0, st>>>(bn, L.list[1], n[1], tris);
         if (n[2]) crt_bvh_bounds_tiny<<<(n[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], n[2], tris);
     };
-    bounds(lists[0], cnt, A);
+    bounds(0, cnt, chunks, A);
     std::vector<std::pair<uint32_t, uint32_t>> levels;
     uint32_t begin = 0, end = (uint32_t)numMeshes;
     CrtTri* src = A; CrtTri* dst = B;
@@ -799,19 +815,30 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     while (end > begin) {
         levels.push_back(std::make_pair(begin, end));
         const CrtBuildLists& L = lists[cur]; const CrtBuildLists& N = lists[cur ^ 1];
-        unsigned long long hp = 0;
-        HIPCHK(hipMemsetAsync(dPacked, 0, sizeof hp, st));
-        if (cnt[0]) { crt_bvh_split<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src);
-                      crt_bvh_partition<<<cnt[0], 1024, 0, st>>>(bn, L.list[0], src, dst, (uint32_t)firstTri, rank, holes, backL, end, dPacked, N); }
-        if (cnt[1]) crt_bvh_mid<<<(cnt[1] + CRT_BVH_WAVES - 1) / CRT_BVH_WAVES, 64 * CRT_BVH_WAVES, 0, st>>>(bn, L.list[1], cnt[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, dPacked, N);
-        if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, dPacked, N);
+        CrtBuildCtl ctl = { 0, 0, 0 };
+        HIPCHK(hipMemsetAsync(dCtl, 0, sizeof ctl, st));
+        if (cnt[0]) {
+            CrtBigScratch* big = bigs[cur]; const uint32_t* cn = chunkNode[cur];
+            crt_bvh_big_bins<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src);
+            crt_bvh_big_sweep<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, dst, chunkL);
+            crt_bvh_big_count<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, chunkL, chunkFR, chunkBL);
+            crt_bvh_big_tables<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, (uint32_t)firstTri, chunkFR, chunkBL, rank, holes, backL);
+            crt_bvh_big_scatter<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, dst, (uint32_t)firstTri, rank, holes, backL, end, dCtl, N, bigs[cur ^ 1], chunkNode[cur ^ 1]);
+        }
+        if (cnt[1]) crt_bvh_mid<<<(cnt[1] + W - 1) / W, 64 * W, 0, st>>>(bn, L.list[1], cnt[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, &dCtl->packed, N);
+        if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, &dCtl->packed, N);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&hp, dPacked, sizeof hp, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&ctl, dCtl, sizeof ctl, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        for (int c = 0; c < 3; ++c) cnt[c] = bvh_unpack(hp, c);
+        if (ctl.degenerate) {                                                      // BVH.cpp:194 hit a BIG node: its permuted triangles go to both buffers
+            crt_bvh_big_degenerate<<<chunks, T, 0, st>>>(bn, L.list[0], bigs[cur], chunkNode[cur], src, dst);
+            crt_bvh_big_degenerate_mark<<<(cnt[0] + 255) / 256, 256, 0, st>>>(bn, L.list[0], bigs[cur], cnt[0]);
+        }
+        for (int c = 0; c < 3; ++c) cnt[c] = bvh_unpack(ctl.packed, c);
+        chunks = ctl.nextChunks;
         const uint32_t newEnd = end + cnt[0] + cnt[1] + cnt[2];
-        if (newEnd > (uint32_t)maxNodes) return CRT_E_OUT_OF_RANGE;
-        bounds(N, cnt, dst);
+        if (newEnd > (uint32_t)maxNodes || cnt[0] > maxBig || chunks > maxChunks) return CRT_E_OUT_OF_RANGE;
+        bounds(cur ^ 1, cnt, chunks, dst);
         begin = end; end = newEnd;
         CrtTri* t = src; src = dst; dst = t;
         cur ^= 1;

@@ -40,6 +40,12 @@ def special_tris(kind, n, seed):
     if kind == "same-centroid":          # boundsMax == boundsMin on every axis: never split, one big leaf
         for k in ("v0", "v1", "v2"):
             t[k] = t[k][0]
+    elif kind in ("degenerate-right", "degenerate-left"):
+        # no candidate plane (one centroid) but n * area > 1e30, so the cost test cannot refuse: upstream "splits" at plane 0 of axis 0,
+        # every triangle lands on one side, the node stays a leaf and its triangles stay permuted (BVH.cpp:194)
+        sgn = np.float32(1.0 if kind == "degenerate-right" else -1.0)
+        t["v0"][:] = np.array([3e15, 1.0, 2.0], np.float32) * sgn; t["v1"][:] = np.array([-1e15, 0.0, 1.0], np.float32) * sgn
+        t["v2"][:] = np.array([5e14, 2.0, -3.0], np.float32) * sgn
     elif kind == "signed-zeros":         # bounds that are +0 / -0 depending on the order of the fold
         z = np.where(rng.rand(n) < 0.5, np.float32(0.0), np.float32(-0.0))
         t["v0"][:, 0] = z; t["v1"][:, 0] = -z; t["v2"][:, 0] = np.abs(rng.normal(size=n)).astype(np.float32)
@@ -62,7 +68,10 @@ def special_tris(kind, n, seed):
 
 CASES = [("random", [1], 1), ("random", [2], 2), ("random", [3, 5, 7], 3), ("random", [500], 4), ("random", [300, 1, 200], 5),
          ("random", [4000, 2500, 1], 7), ("random", [70000], 8), ("same-centroid", [200], 9), ("signed-zeros", [3000], 10),
-         ("two-clusters", [1000], 11), ("grid", [5000, 3000], 12), ("sorted", [6000], 13), ("reversed", [6000], 14)]
+         ("two-clusters", [1000], 11), ("grid", [5000, 3000], 12), ("sorted", [6000], 13), ("reversed", [6000], 14),
+         # nodes cut into chunks (> 2048 triangles): leaf by the cost test, zero bounds, empty bins, the failed partition, deep levels of chunks
+         ("same-centroid", [5000], 15), ("signed-zeros", [20000], 16), ("two-clusters", [9000], 17), ("degenerate-right", [5000], 18),
+         ("degenerate-left", [5000], 19), ("degenerate-right", [300, 6, 2049], 20), ("grid", [40000, 2049, 2048], 21), ("random", [200000, 9, 8], 22)]
 
 
 @pytest.fixture
@@ -80,6 +89,8 @@ def test_device_build_bit_identical(session, kind, counts, seed):
     assert du == ou and np.array_equal(dr, oroots)
     assert dt_.tobytes() == ot.tobytes()
     assert dn.tobytes() == on.tobytes()
+    if kind.startswith("degenerate"):
+        assert du == len(counts) and ot.tobytes() != tris.tobytes()   # one leaf per mesh, and the failed partition did move triangles
     if kind == "random" and sum(counts) > 100:
         check_invariants(dn, dr, dt_, counts)
 
