@@ -18,8 +18,13 @@
 //    which two prefix sums and two small tables evaluate in parallel. It also covers the degenerate partitions
 //    (L == 0 or L == n) after which upstream keeps the node a leaf but leaves its triangles permuted.
 //  * nodes are numbered by the recursion (children = next two free indices, then the whole left subtree, then the
-//    right one): once the tree is known, index(left) = base, index(right) = base+1, base(left) = base+2,
-//    base(right) = base+2+descendants(left), top-down from each mesh's root.
+//    right one): index(left) = base, index(right) = base+1, base(left) = base+2, base(right) = base+2+descendants(left).
+//    A subtree with k leaves has 2k-1 nodes, and the leaves left of a node inside its mesh are exactly those of the left
+//    siblings along its path, so with S = exclusive prefix count of leaf starts over the triangle pool
+//        base(P) = index(root) + 1 + 2 depth(P) + 2 (S[first(P)] - S[first(root)]) - 2 rightTurns(P)
+//        index(P) = base(P) - 2 for a left child, base(P) + 1 - 2 (S[first(P)] - S[first(left sibling)]) for a right child
+//        index(root of mesh m) = firstNode + 2 S[first(root)] - m
+//    -- one scan and one pass over the nodes once the tree is known (r2 ran two launches per level for this).
 // Triangles move between two buffers, one level per pass; a finished leaf's segment is written to both.
 #pragma once
 #include "crt_device.h"
@@ -33,9 +38,9 @@ struct CrtBuildNode {
     float bmin[3], bmax[3];          // UpdateNodeBounds
     float splitPos; int axis;
     uint32_t state;                  // 0 = undecided, 1 = split, 2 = leaf, 3 = leaf whose triangles the failed partition permuted
-    uint32_t desc;                   // number of descendant nodes
-    uint32_t index, base;            // final node index; first free index when this node was subdivided
-    uint32_t pad;
+    uint32_t mesh;                   // mesh (root) this node belongs to
+    uint32_t depth, rightTurns;      // of the path from the root: what the closed-form numbering needs
+    uint32_t isRight;                // 1 = right child (its left sibling is the build node before it)
 };
 
 __device__ __forceinline__ const float* bvh_tri_f(const CrtTri* t, size_t i) { return reinterpret_cast<const float*>(t + i); }
@@ -94,10 +99,10 @@ __device__ __forceinline__ void bvh_new_children(CrtBuildNode* nodes, CrtBuildNo
     const uint32_t id = levelEnd + bvh_unpack(before, 0) + bvh_unpack(before, 1) + bvh_unpack(before, 2);
     node.left = id; node.right = id + 1;
     CrtBuildNode c;
-    c.left = c.right = CRT_BVH_NONE; c.splitPos = 0.0f; c.axis = 0; c.state = 0; c.desc = 0; c.index = 0; c.base = 0; c.pad = 0;
+    c.left = c.right = CRT_BVH_NONE; c.splitPos = 0.0f; c.axis = 0; c.state = 0; c.mesh = node.mesh; c.depth = node.depth + 1; c.rightTurns = node.rightTurns; c.isRight = 0;
     for (int k = 0; k < 3; ++k) { c.bmin[k] = 1e30f; c.bmax[k] = -1e30f; }
     c.first = first; c.count = L; nodes[id] = c;
-    c.first = first + L; c.count = n - L; nodes[id + 1] = c;
+    c.first = first + L; c.count = n - L; c.rightTurns = node.rightTurns + 1; c.isRight = 1; nodes[id + 1] = c;
     const int cl = bvh_class(L), cr = bvh_class(n - L);
     next.list[cl][bvh_unpack(before, cl)] = id;
     next.list[cr][bvh_unpack(before + bvh_pack_one(cl), cr)] = id + 1;
@@ -232,7 +237,7 @@ __global__ void crt_bvh_init_roots(CrtBuildNode* __restrict__ nodes, const uint3
         CrtBuildNode n;
         n.first = cur; n.count = meshTriCounts[m]; n.left = n.right = CRT_BVH_NONE;
         for (int c = 0; c < 3; ++c) { n.bmin[c] = 1e30f; n.bmax[c] = -1e30f; }
-        n.splitPos = 0.0f; n.axis = 0; n.state = 0; n.desc = 0; n.index = 0; n.base = 0; n.pad = 0;
+        n.splitPos = 0.0f; n.axis = 0; n.state = 0; n.mesh = (uint32_t)m; n.depth = 0; n.rightTurns = 0; n.isRight = 0;
         nodes[m] = n;
         cur += meshTriCounts[m];
         if (bvh_class(n.count) == CRT_BVH_CLASS_BIG) {
@@ -839,47 +844,81 @@ __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* _
     if (split) bvh_new_children(nodes, node, first, L, n, levelEnd, base + CRT_BVH_PACK_TINY(2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull))), next);
 }
 
-// descendants, bottom-up: one launch per level, deepest first
-__global__ void crt_bvh_count_desc(CrtBuildNode* __restrict__ nodes, uint32_t begin, uint32_t count)
+// ---- numbering and emission (closed form, see the header) ----
+__global__ void crt_bvh_leaf_flags(const CrtBuildNode* __restrict__ nodes, uint32_t count, uint32_t poolFirst, uint32_t* __restrict__ flags)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
-    CrtBuildNode& n = nodes[begin + k];
-    n.desc = n.left == CRT_BVH_NONE ? 0u : 2u + nodes[n.left].desc + nodes[n.right].desc;
+    if (nodes[k].left == CRT_BVH_NONE) flags[nodes[k].first - poolFirst] = 1u;
 }
 
-// roots are numbered mesh after mesh: BVH.cpp:238-251 (root = next free index, then its whole subtree)
-__global__ void crt_bvh_number_roots(CrtBuildNode* __restrict__ nodes, int numMeshes, uint32_t firstNode, uint32_t* __restrict__ roots, uint32_t* __restrict__ nodesUsed)
+// exclusive prefix sum of n words into S[0 .. n] (S[n] = total): per-workgroup sums, one workgroup over the sums, then the scan proper.
+// Launch crt_bvh_scan_sums and crt_bvh_scan_apply with n / CRT_BVH_SCAN_ITEMS + 1 workgroups (position n must be covered).
+#define CRT_BVH_SCAN_THREADS 256
+#define CRT_BVH_SCAN_PER_THREAD 16
+#define CRT_BVH_SCAN_ITEMS (CRT_BVH_SCAN_THREADS * CRT_BVH_SCAN_PER_THREAD)
+__global__ void __launch_bounds__(CRT_BVH_SCAN_THREADS) crt_bvh_scan_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t cur = firstNode;
-    for (int m = 0; m < numMeshes; ++m) {
-        nodes[m].index = cur; nodes[m].base = cur + 1; roots[m] = cur;
-        cur += 1u + nodes[m].desc;
+    __shared__ uint32_t s_red[CRT_BVH_SCAN_THREADS / 64];
+    const uint32_t base = blockIdx.x * CRT_BVH_SCAN_ITEMS;
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < CRT_BVH_SCAN_ITEMS; i += blockDim.x) if (base + i < n) v += in[base + i];
+    v = bvh_block_sum(v, s_red);
+    if (threadIdx.x == 0) sums[blockIdx.x] = v;
+}
+__global__ void __launch_bounds__(CRT_BVH_SCAN_THREADS) crt_bvh_scan_blocks(uint32_t* __restrict__ sums, uint32_t nb)
+{
+    __shared__ uint32_t s_part[CRT_BVH_SCAN_THREADS];
+    const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = threadIdx.x * per, hi = (lo + per) < nb ? (lo + per) : nb;
+    uint32_t v = 0;
+    for (uint32_t i = lo; i < hi; ++i) v += sums[i];
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t t = 0; t < threadIdx.x; ++t) before += s_part[t];
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t x = sums[i]; sums[i] = before; before += x; }
+}
+__global__ void __launch_bounds__(CRT_BVH_SCAN_THREADS) crt_bvh_scan_apply(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ sums, uint32_t* __restrict__ S)
+{
+    __shared__ uint32_t s_part[CRT_BVH_SCAN_THREADS];
+    const uint32_t base = blockIdx.x * CRT_BVH_SCAN_ITEMS + threadIdx.x * CRT_BVH_SCAN_PER_THREAD;
+    uint32_t x[CRT_BVH_SCAN_PER_THREAD], v = 0;
+#pragma unroll
+    for (int i = 0; i < CRT_BVH_SCAN_PER_THREAD; ++i) { x[i] = (base + i < n) ? in[base + i] : 0u; v += x[i]; }
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    uint32_t before = sums[blockIdx.x];
+    for (uint32_t t = 0; t < threadIdx.x; ++t) before += s_part[t];
+#pragma unroll
+    for (int i = 0; i < CRT_BVH_SCAN_PER_THREAD; ++i) { if (base + i < n) S[base + i] = before; before += x[i]; }
+    if (base <= n && n < base + CRT_BVH_SCAN_PER_THREAD) {     // the thread whose range ends at or contains n writes the total
+        uint32_t t = sums[blockIdx.x];
+        for (uint32_t u = 0; u < threadIdx.x; ++u) t += s_part[u];
+        for (uint32_t i = 0; base + i < n; ++i) t += x[i];
+        S[n] = t;
     }
-    *nodesUsed = cur - firstNode;
 }
 
-// top-down, one launch per level: SubdivideBVH's allocation order (BVH.cpp:203-215)
-__global__ void crt_bvh_number_children(CrtBuildNode* __restrict__ nodes, uint32_t begin, uint32_t count)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
-    const CrtBuildNode& n = nodes[begin + k];
-    if (n.left == CRT_BVH_NONE) return;
-    CrtBuildNode& l = nodes[n.left]; CrtBuildNode& r = nodes[n.right];
-    l.index = n.base; r.index = n.base + 1;
-    l.base = n.base + 2; r.base = n.base + 2 + l.desc;
-}
-
-__global__ void crt_bvh_emit(const CrtBuildNode* __restrict__ nodes, uint32_t count, CrtBVHNode* __restrict__ out)
+// every build node gets its final index and is written out as a reference-layout BVHNode; roots[m] and the node count too
+__global__ void crt_bvh_emit(const CrtBuildNode* __restrict__ nodes, uint32_t count, int numMeshes, const uint32_t* __restrict__ S, uint32_t poolFirst, uint32_t poolCount,
+                             uint32_t firstNode, CrtBVHNode* __restrict__ out, uint32_t* __restrict__ roots, uint32_t* __restrict__ nodesUsed)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
     const CrtBuildNode& n = nodes[k];
+    const uint32_t rootFirst = nodes[n.mesh].first;           // the roots are build nodes 0 .. numMeshes
+    const uint32_t rootIndex = firstNode + 2u * S[rootFirst - poolFirst] - n.mesh;
+    const uint32_t base = rootIndex + 1u + 2u * n.depth + 2u * (S[n.first - poolFirst] - S[rootFirst - poolFirst]) - 2u * n.rightTurns;
+    uint32_t index;
+    if (n.depth == 0) index = rootIndex;
+    else if (!n.isRight) index = base - 2u;
+    else index = base + 1u - 2u * (S[n.first - poolFirst] - S[nodes[k - 1].first - poolFirst]);
     CrtBVHNode o;
     for (int c = 0; c < 3; ++c) { o.aabbMin[c] = n.bmin[c]; o.aabbMax[c] = n.bmax[c]; }
     if (n.left == CRT_BVH_NONE) { o.leftFirst = n.first; o.triCount = n.count; }
-    else { o.leftFirst = nodes[n.left].index; o.triCount = 0; }
-    out[n.index] = o;
+    else { o.leftFirst = base; o.triCount = 0; }
+    out[index] = o;
+    if (n.depth == 0) roots[n.mesh] = rootIndex;
+    if (k == 0) *nodesUsed = 2u * S[poolCount] - (uint32_t)numMeshes;
 }

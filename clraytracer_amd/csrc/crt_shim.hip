@@ -753,7 +753,8 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     const size_t offBig = (offLists + 6 * listCap * sizeof(uint32_t) + 255) & ~(size_t)255;
     const size_t offChunks = (offBig + 2 * maxBig * sizeof(CrtBigScratch) + 255) & ~(size_t)255;
     const size_t offSmall = (offChunks + 5 * maxChunks * sizeof(uint32_t) + 255) & ~(size_t)255;
-    const size_t need = offSmall + (2 * (size_t)numMeshes + 8) * sizeof(uint32_t) + sizeof(CrtBuildCtl) + 16;
+    const int kCtlLevels = 256;                                                    // one zeroed control record per level up to here (one memset); deeper levels reuse the last one
+    const size_t need = offSmall + (2 * (size_t)numMeshes + 8) * sizeof(uint32_t) + kCtlLevels * sizeof(CrtBuildCtl) + 16;
     if (need > g.buildBytes) {
         if (g.buildBuf) (void)hipFree(g.buildBuf);
         g.buildBuf = nullptr; g.buildBytes = 0;
@@ -776,8 +777,9 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     uint32_t* dCounts = reinterpret_cast<uint32_t*>(base + offSmall);
     uint32_t* dRoots = dCounts + numMeshes;
     uint32_t* dScal = dRoots + numMeshes;                                          // [0] nodes used
-    CrtBuildCtl* dCtl = reinterpret_cast<CrtBuildCtl*>((reinterpret_cast<uintptr_t>(dScal + 2) + 15) & ~(uintptr_t)15);   // next level's list sizes and chunk count (crt_bvh_build.h)
+    CrtBuildCtl* dCtls = reinterpret_cast<CrtBuildCtl*>((reinterpret_cast<uintptr_t>(dScal + 2) + 15) & ~(uintptr_t)15);  // per level: next level's list sizes and chunk count (crt_bvh_build.h)
     hipStream_t st = g.stream;
+    HIPCHK(hipMemsetAsync(dCtls, 0, kCtlLevels * sizeof(CrtBuildCtl), st));
     HIPCHK(hipMemcpyAsync(dCounts, meshTriCounts, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     // level 0 = the roots, classified here
     uint32_t cnt[3] = { 0, 0, 0 };
@@ -808,15 +810,15 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         if (n[2]) crt_bvh_bounds_tiny<<<(n[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], n[2], tris);
     };
     bounds(0, cnt, chunks, A);
-    std::vector<std::pair<uint32_t, uint32_t>> levels;
     uint32_t begin = 0, end = (uint32_t)numMeshes;
     CrtTri* src = A; CrtTri* dst = B;
-    int cur = 0;
+    int cur = 0, level = 0;
     while (end > begin) {
-        levels.push_back(std::make_pair(begin, end));
         const CrtBuildLists& L = lists[cur]; const CrtBuildLists& N = lists[cur ^ 1];
         CrtBuildCtl ctl = { 0, 0, 0 };
-        HIPCHK(hipMemsetAsync(dCtl, 0, sizeof ctl, st));
+        CrtBuildCtl* dCtl = dCtls + (level < kCtlLevels ? level : kCtlLevels - 1);
+        if (level >= kCtlLevels - 1) HIPCHK(hipMemsetAsync(dCtl, 0, sizeof ctl, st));   // the shared last record (zero already on its first use: harmless)
+        ++level;
         if (cnt[0]) {
             CrtBigScratch* big = bigs[cur]; const uint32_t* cn = chunkNode[cur];
             crt_bvh_big_bins<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src);
@@ -844,27 +846,28 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         cur ^= 1;
     }
     const uint32_t numBuilt = end;
-    for (size_t l = levels.size(); l-- > 0;) {
-        const uint32_t c = levels[l].second - levels[l].first;
-        crt_bvh_count_desc<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
+    if (firstNode + numBuilt > g.nodeCap) return CRT_E_OUT_OF_RANGE;
+    // numbering in closed form (crt_bvh_build.h): leaf starts -> exclusive prefix counts S (flags in `rank`, S in `holes`..: total + 1 words) -> one pass
+    {
+        uint32_t* flags = rank; uint32_t* S = holes; uint32_t* sums = chunkL;
+        const uint32_t nb = (uint32_t)(total / CRT_BVH_SCAN_ITEMS) + 1;
+        if (nb > maxChunks) return CRT_E_OUT_OF_RANGE;
+        HIPCHK(hipMemsetAsync(flags, 0, total * sizeof(uint32_t), st));
+        crt_bvh_leaf_flags<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, (uint32_t)firstTri, flags);
+        crt_bvh_scan_sums<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums);
+        crt_bvh_scan_blocks<<<1, CRT_BVH_SCAN_THREADS, 0, st>>>(sums, nb);
+        crt_bvh_scan_apply<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums, S);
+        crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, numMeshes, S, (uint32_t)firstTri, (uint32_t)total, (uint32_t)firstNode, g.rawNodes, dRoots, dScal);
+        HIPCHK(hipGetLastError());
     }
-    crt_bvh_number_roots<<<1, 1, 0, st>>>(bn, numMeshes, (uint32_t)firstNode, dRoots, dScal);
-    for (size_t l = 0; l < levels.size(); ++l) {
-        const uint32_t c = levels[l].second - levels[l].first;
-        crt_bvh_number_children<<<(c + 255) / 256, 256, 0, st>>>(bn, levels[l].first, c);
-    }
-    HIPCHK(hipGetLastError());
     uint32_t used = 0;
     HIPCHK(hipMemcpyAsync(&used, dScal, sizeof used, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (used != numBuilt || firstNode + used > g.nodeCap) return CRT_E_OUT_OF_RANGE;
-    crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, g.rawNodes);
-    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(g.roots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(g.hRoots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     crt_relayout_tris<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.rawTris, firstTri, total, g.triHot, g.triCold);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    if (used != numBuilt) return CRT_E_OUT_OF_RANGE;                               // the closed form and the level loop disagree: never seen, would mean a damaged tree
     if (firstNode + used > g.nodeCount) g.nodeCount = (uint32_t)(firstNode + used);
     if (firstMesh + (size_t)numMeshes > g.numRoots) g.numRoots = (uint32_t)(firstMesh + (size_t)numMeshes);
     if (nodesUsedOut) *nodesUsedOut = used;
