@@ -738,6 +738,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     if (firstTri + total > g.trisHigh) return CRT_E_BAD_ARGUMENT;                  // triangles must have been uploaded
     if (firstTri + total > 0x00FFFFFFu) return CRT_E_OUT_OF_RANGE;                 // leaf references carry 24-bit triangle indices
     if (firstNode + 2 * total > g.nodeCap) return CRT_E_OUT_OF_RANGE;              // a mesh of n triangles needs at most 2n-1 nodes
+    if (total / CRT_BVH_SMALL >= 4096 || total / CRT_BVH_TINY >= (1u << 20)) return CRT_E_OUT_OF_RANGE;   // field widths of the packed per-level counter (crt_bvh_build.h)
     RCCHK(sync_all());
 
     // second triangle pool (allocated on first use, indexed like rawTris) and scratch:

@@ -69,9 +69,9 @@ def special_tris(kind, n, seed):
 CASES = [("random", [1], 1), ("random", [2], 2), ("random", [3, 5, 7], 3), ("random", [500], 4), ("random", [300, 1, 200], 5),
          ("random", [4000, 2500, 1], 7), ("random", [70000], 8), ("same-centroid", [200], 9), ("signed-zeros", [3000], 10),
          ("two-clusters", [1000], 11), ("grid", [5000, 3000], 12), ("sorted", [6000], 13), ("reversed", [6000], 14),
-         # nodes cut into chunks (> 2048 triangles): leaf by the cost test, zero bounds, empty bins, the failed partition, deep levels of chunks
+         # nodes cut into chunks (> 1024 triangles): leaf by the cost test, zero bounds, empty bins, the failed partition, deep levels of chunks
          ("same-centroid", [5000], 15), ("signed-zeros", [20000], 16), ("two-clusters", [9000], 17), ("degenerate-right", [5000], 18),
-         ("degenerate-left", [5000], 19), ("degenerate-right", [300, 6, 2049], 20), ("grid", [40000, 2049, 2048], 21), ("random", [200000, 9, 8], 22)]
+         ("degenerate-left", [5000], 19), ("degenerate-right", [300, 6, 1025], 20), ("grid", [40000, 1025, 1024], 21), ("random", [200000, 9, 8], 22)]
 
 
 @pytest.fixture

@@ -20,7 +20,7 @@ import oracle_lib  # noqa: E402
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 KINDS = ["random", "grid", "signed-zeros", "two-clusters", "same-centroid", "sorted", "reversed", "degenerate-right", "degenerate-left"]
-SIZES = [1, 2, 3, 8, 9, 17, 64, 65, 128, 129, 700, 2048, 2049, 3000, 5000, 9000, 20000, 60000]
+SIZES = [1, 2, 3, 8, 9, 17, 64, 65, 128, 129, 700, 1024, 1025, 2048, 2049, 3000, 5000, 9000, 20000, 60000]
 t0 = time.time()
 tot = {"builds": 0, "meshes": 0, "tris": 0, "nodes": 0, "leaf3": 0}
 with driver.Session(64, 48, device=0) as s:
