@@ -738,16 +738,13 @@ __global__ void crt_bvh_bounds_tiny(CrtBuildNode* __restrict__ nodes, const uint
 // binned left/right of it -- the same values upstream gets by growing bin boxes and merging them in sweep order
 // (min/max are exact; an empty side keeps the (1e30, -1e30) box and its NaN cost, as upstream). The partition loop
 // runs literally on a nibble-packed index permutation.
-__global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
-                             uint32_t levelEnd, unsigned long long* __restrict__ packed, CrtBuildLists next)
+template <int N>
+__device__ __forceinline__ void bvh_tiny_body(CrtBuildNode* __restrict__ nodes, CrtBuildNode& node, const bool live, const uint32_t first, const uint32_t n,
+                                              CrtTri* __restrict__ src, CrtTri* __restrict__ dst, uint32_t levelEnd, unsigned long long* __restrict__ packed, const CrtBuildLists& next)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = k < count;
-    CrtBuildNode& node = nodes[list[live ? k : 0]];           // lanes past the end idle through the code (n = 0) so the wave stays converged
-    const uint32_t first = node.first, n = live ? node.count : 0u;
-    float tmn[CRT_BVH_TINY][3], tmx[CRT_BVH_TINY][3], cen[CRT_BVH_TINY][3];
+    float tmn[N][3], tmx[N][3], cen[N][3];
 #pragma unroll
-    for (int i = 0; i < CRT_BVH_TINY; ++i) {
+    for (int i = 0; i < N; ++i) {
         if ((uint32_t)i < n) {
             const float* t = bvh_tri_f(src, (size_t)first + i);
 #pragma unroll
@@ -767,13 +764,13 @@ __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* _
     for (int a = 0; a < 3; ++a) {
         float boundsMin = 1e30f, boundsMax = -1e30f;
 #pragma unroll
-        for (int i = 0; i < CRT_BVH_TINY; ++i)
+        for (int i = 0; i < N; ++i)
             if ((uint32_t)i < n) { const float v = cen[i][a]; boundsMin = boundsMin < v ? boundsMin : v; boundsMax = boundsMax > v ? boundsMax : v; }
         if (boundsMax == boundsMin) continue;
         const float scale = (float)CRT_BVH_BINS / (boundsMax - boundsMin);
-        int bin[CRT_BVH_TINY];
+        int bin[N];
 #pragma unroll
-        for (int i = 0; i < CRT_BVH_TINY; ++i) {
+        for (int i = 0; i < N; ++i) {
             int b = f2i((cen[i][a] - boundsMin) * scale);
             b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
             if (b < 0) b = 0;
@@ -786,7 +783,7 @@ __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* _
             float lmn[3] = { 1e30f, 1e30f, 1e30f }, lmx[3] = { -1e30f, -1e30f, -1e30f };
             float rmn[3] = { 1e30f, 1e30f, 1e30f }, rmx[3] = { -1e30f, -1e30f, -1e30f };
 #pragma unroll
-            for (int i = 0; i < CRT_BVH_TINY; ++i) {
+            for (int i = 0; i < N; ++i) {
                 const bool isL = bin[i] <= p, isR = bin[i] > p && bin[i] < CRT_BVH_BINS;
                 leftCount += isL ? 1 : 0; rightCount += isR ? 1 : 0;
 #pragma unroll
@@ -809,11 +806,11 @@ __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* _
     // the partition loop (BVH.cpp:185-192) on an index permutation packed four bits per entry, then one copy per triangle
     uint32_t left = 0;                                         // bit i: centroid of triangle i is left of the plane
 #pragma unroll
-    for (int i = 0; i < CRT_BVH_TINY; ++i) {
+    for (int i = 0; i < N; ++i) {
         const float c = bestAxis == 0 ? cen[i][0] : (bestAxis == 1 ? cen[i][1] : cen[i][2]);
         if ((uint32_t)i < n && c < splitPos) left |= 1u << i;
     }
-    static_assert(CRT_BVH_TINY <= 16, "the permutation is packed four bits per entry into 64 bits");
+    static_assert(N <= 16 && N <= CRT_BVH_TINY, "the permutation is packed four bits per entry into 64 bits");
     unsigned long long perm = 0xFEDCBA9876543210ull;
     int i = 0, j = (live && !isLeaf) ? (int)n - 1 : -1;
     while (i <= j) {
@@ -842,6 +839,19 @@ __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* _
     if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(packed, CRT_BVH_PACK_TINY(2u * (uint32_t)__popcll(m)));
     base = (unsigned long long)__shfl((long long)base, __ffsll((long long)m) - 1, 64);
     if (split) bvh_new_children(nodes, node, first, L, n, levelEnd, base + CRT_BVH_PACK_TINY(2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull))), next);
+}
+
+// The fully unrolled body costs the same for 2 triangles as for 8, so a wave whose largest node has at most 4 (most waves of the
+// deepest levels) runs the 4-triangle instantiation: half the instructions.
+__global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, CrtTri* __restrict__ src, CrtTri* __restrict__ dst,
+                             uint32_t levelEnd, unsigned long long* __restrict__ packed, CrtBuildLists next)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = k < count;
+    CrtBuildNode& node = nodes[list[live ? k : 0]];           // lanes past the end idle through the code (n = 0) so the wave stays converged
+    const uint32_t first = node.first, n = live ? node.count : 0u;
+    if (bvh_wave_max(n) <= 4u) bvh_tiny_body<4>(nodes, node, live, first, n, src, dst, levelEnd, packed, next);
+    else bvh_tiny_body<CRT_BVH_TINY>(nodes, node, live, first, n, src, dst, levelEnd, packed, next);
 }
 
 // ---- numbering and emission (closed form, see the header) ----
