@@ -149,6 +149,9 @@ struct CrtDevScene {
     uint32_t tlasNodes;                      // 0: no tree (few instances, or none cullable)
     const uint32_t* __restrict__ alwaysList; // instances that are never culled (single-leaf meshes, unbounded), ascending
     uint32_t numAlways;
+#ifdef CRT_EXP_TOPCOUNT
+    uint32_t topPairs;                       // experiment: pair records below this index count as "top of a tree" (tools/layout_experiment.py)
+#endif
 };
 
 struct CrtFrame {
@@ -428,6 +431,9 @@ struct Traversal {
         {
             const float4* p = S.pairs + (size_t)ref * 4;        // one aligned 64-byte record
             lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
+#ifdef CRT_EXP_TOPCOUNT
+            if (COUNT) { const bool top = ref < S.topPairs; lc.shadowRays++; if (top) lc.stackOverflows++; if (__ballot(!top) == 0) lc.shadowHits++; }
+#endif
         }
         if (COUNT) lc.innerVisits++;
         float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
