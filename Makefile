@@ -26,7 +26,7 @@ tools/ubench/gather: tools/ubench/gather.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ $<
 # dependent-chain 64-B gather microbenchmark: the ceiling bench.py's roofline.chain is taken against (profiles/r03_ubench_chain.*)
 tools/ubench/chain: tools/ubench/chain.hip
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -o $@ $<
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -Wno-unused-value -Wno-uninitialized -Wno-sometimes-uninitialized -o $@ $<
 
 # the reference's EngineMain loop over the mirrored C++ API
 $(EXAMPLE): examples/headless_main.cpp $(HOST_SO)

@@ -32,18 +32,6 @@
 #include "../../include/crt_types.h"
 
 #define CRT_LEAF_BIT 0x80000000u
-#ifndef CRT_WAVE_OVF_TEST
-#define CRT_WAVE_OVF_TEST 1
-#endif
-#ifndef CRT_FLAT_CF
-#define CRT_FLAT_CF 1
-#endif
-#ifndef CRT_SELECT_SWAP
-#define CRT_SELECT_SWAP 1
-#endif
-#ifndef CRT_SCALAR_INNER
-#define CRT_SCALAR_INNER 1     // 1: scalar fetch for wave-uniform nodes in both inner steps of a trip; 2: in the first only; 0: never
-#endif
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
 #ifndef CRT_WAVES_PER_SIMD
 #define CRT_WAVES_PER_SIMD 8   // 32 waves per CU: 64 VGPRs (the trace kernel fits them without scratch) and 5 KiB of LDS each = the CU's 160 KiB
@@ -91,18 +79,14 @@ struct CrtStackT {
     __device__ __forceinline__ void write(int slot, uint32_t v) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
-#if CRT_WAVE_OVF_TEST
         if (kLds >= CRT_STACK_DEPTH || __ballot(s >= kLds) == 0) { lds[s * 64] = v; return; }
-#endif
         if (kLds >= CRT_STACK_DEPTH || s < kLds) lds[s * 64] = v;
         else *overflow_slot(s - kLds) = v;
     }
     __device__ __forceinline__ uint32_t read(int slot) const
     {
         const int s = slot & (CRT_STACK_DEPTH - 1);
-#if CRT_WAVE_OVF_TEST
         if (kLds >= CRT_STACK_DEPTH || __ballot(s >= kLds) == 0) return lds[s * 64];
-#endif
         if (kLds >= CRT_STACK_DEPTH || s < kLds) return lds[s * 64];
         return *overflow_slot(s - kLds);
     }
@@ -149,9 +133,6 @@ struct CrtDevScene {
     uint32_t tlasNodes;                      // 0: no tree (few instances, or none cullable)
     const uint32_t* __restrict__ alwaysList; // instances that are never culled (single-leaf meshes, unbounded), ascending
     uint32_t numAlways;
-#ifdef CRT_EXP_TOPCOUNT
-    uint32_t topPairs;                       // experiment: pair records below this index count as "top of a tree" (tools/layout_experiment.py)
-#endif
 };
 
 struct CrtFrame {
@@ -311,16 +292,13 @@ __device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
 __device__ __forceinline__ CrtDevInstance load_instance(const CrtDevInstance* __restrict__ table, uint32_t inst)
 {
     CrtDevInstance I;
-#ifndef CRT_NO_SCALAR_ENTER
     const uint32_t inst0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)inst);
     if (__ballot(inst != inst0) == 0) {
         const crt_const_f32x4_ptr p = (crt_const_f32x4_ptr)(table + inst0);
         const crt_f32x4 a = p[0], b = p[1], c = p[2], e = p[3];
         I.r0 = make_float4(a.x, a.y, a.z, a.w); I.r1 = make_float4(b.x, b.y, b.z, b.w);
         I.r2 = make_float4(c.x, c.y, c.z, c.w); I.r3 = make_float4(e.x, e.y, e.z, e.w);
-    } else
-#endif
-    {
+    } else {
         const CrtDevInstance* ip = table + inst;
         I.r0 = ip->r0; I.r1 = ip->r1; I.r2 = ip->r2; I.r3 = ip->r3;
     }
@@ -343,9 +321,6 @@ struct Traversal {
     v3 mo, md, inv;               // ray in the current instance's object space (direction not renormalised, hazard H6)
     Triout tr;                    // running best of the current instance (kernel_main.cl:200-202)
     int sp, prot, inters;         // stack pointer, pop counter (kernel_main.cl:131), OR of the `passed` flags
-#ifdef CRT_PREFETCH_FAR
-    uint32_t pf;                  // experiment: destination of the one-dword touch of a pushed child's record
-#endif
     uint32_t ref, curInst;
     bool active;                  // inside an instance
 
@@ -354,9 +329,6 @@ struct Traversal {
         mo = mk3(0.f, 0.f, 0.f); md = mo; inv = mo;
         tr.t = 0.f; tr.u = 0.f; tr.v = 0.f; tr.tri = 0;
         sp = 0; prot = 0; inters = 0; ref = 0; curInst = 0; active = false;
-#ifdef CRT_PREFETCH_FAR
-        pf = 0;
-#endif
     }
     __device__ __forceinline__ bool at_inner() const { return active && !(ref & CRT_LEAF_BIT); }
     __device__ __forceinline__ bool at_leaf() const { return active && (ref & CRT_LEAF_BIT); }
@@ -371,8 +343,7 @@ struct Traversal {
     template <class STK>
     __device__ __forceinline__ void pop_next(const STK& stack, Closest& c, LaneCounters& lc)
     {
-#if CRT_FLAT_CF
-        // the same decisions with one level of branching: `protection++` happens exactly when the stack is not empty
+        // one level of branching: `protection++` happens exactly when the stack is not empty
         const bool nonEmpty = sp > 0, canPop = nonEmpty && prot < CRT_MAX_POPS;
         prot += nonEmpty ? 1 : 0;
         if (COUNT) { if (nonEmpty && !canPop) lc.capHits++; if (canPop) lc.pops++; }
@@ -383,19 +354,8 @@ struct Traversal {
             c.hit.t = keep ? tr.t : c.hit.t; c.hit.u = keep ? tr.u : c.hit.u; c.hit.v = keep ? tr.v : c.hit.v; c.hit.tri = keep ? tr.tri : c.hit.tri;
             active = false;
         }
-#else
-        if (sp > 0) {
-            if (!(prot++ < CRT_MAX_POPS)) { if (COUNT) lc.capHits++; finish(c); }
-            else { if (COUNT) lc.pops++; --sp; ref = stack.read(sp); }
-        } else finish(c);
-#endif
     }
-    // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root
-    // The instance record comes through a SCALAR load (one s_load_dwordx16 through the scalar cache) when every lane that
-    // enters an instance in this step enters the same one -- the common case for a coherent packet, whose lanes share their
-    // first candidates -- and through four per-lane vector loads otherwise: vector-memory instructions are what bounds the
-    // kernel, and unlike the node fetches (where the same test cost more than it saved, round 2) entries are rare
-    // enough for one readfirstlane + compare + ballot per entering step to pay.
+    // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root (record fetch: load_instance above)
     __device__ __forceinline__ void enter(const CrtDevScene& S, uint32_t inst, v3 o, v3 d, float bestSoFar, LaneCounters& lc)
     {
         curInst = inst;
@@ -409,11 +369,10 @@ struct Traversal {
         if (COUNT) { lc.traversals++; lc.pops++; }
     }
     // kernel_main.cl:142-157: fetch the child pair, two slab tests, near child first, far child pushed
-    template <bool TRY_SCALAR, class STK>
+    template <class STK>
     __device__ __forceinline__ void inner(const CrtDevScene& S, const STK& stack, Closest& c, LaneCounters& lc)
     {
         float4 lmin, lmax, rmin, rmax;
-#if CRT_SCALAR_INNER
         // every lane of this step on the same node (the top of a tree under a coherent packet): one scalar load instead of four
         // vector loads, the boxes as scalar operands. (Round 2 measured the same idea as a wash -- the uniformity test costs every
         // step -- but with the instance bounds and records on the scalar path the node fetches are 3/4 of the vector-memory
@@ -421,41 +380,25 @@ struct Traversal {
         // frames +0...5 %. The same for leaves -- a uniform triangle through scalar loads -- lost 18 %: the 9 scalar operands push the
         // kernel into scratch, and small triangles are never shared by a whole packet.)
         const uint32_t ref0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
-        if (TRY_SCALAR && __ballot(ref != ref0) == 0) {
+        if (__ballot(ref != ref0) == 0) {
             const crt_const_f32x4_ptr q = (crt_const_f32x4_ptr)(S.pairs + (size_t)ref0 * 4);
             const crt_f32x4 a = q[0], b = q[1], c4 = q[2], e = q[3];
             lmin = make_float4(a.x, a.y, a.z, a.w); lmax = make_float4(b.x, b.y, b.z, b.w);
             rmin = make_float4(c4.x, c4.y, c4.z, c4.w); rmax = make_float4(e.x, e.y, e.z, e.w);
-        } else
-#endif
-        {
+        } else {
             const float4* p = S.pairs + (size_t)ref * 4;        // one aligned 64-byte record
             lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
-#ifdef CRT_EXP_TOPCOUNT
-            if (COUNT) { const bool top = ref < S.topPairs; lc.shadowRays++; if (top) lc.stackOverflows++; if (__ballot(!top) == 0) lc.shadowHits++; }
-#endif
         }
         if (COUNT) lc.innerVisits++;
         float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
         float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
-#ifdef CRT_PREFETCH_FAR
-        asm volatile("" : "+v"(pf));      // the touch issued by an earlier step has landed by now (loads return in order): its register may be reused
-#endif
         uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
-#if CRT_SELECT_SWAP
         {   // kernel_main.cl:148-151 as four selects on one compare (the branchy form costs an exec-mask save / restore)
             const bool sw = dist1 > dist2;
             const float d1 = sw ? dist2 : dist1, d2 = sw ? dist1 : dist2;
             const uint32_t r1 = sw ? farRef : nearRef, r2 = sw ? nearRef : farRef;
             dist1 = d1; dist2 = d2; nearRef = r1; farRef = r2;
         }
-#else
-        if (dist1 > dist2) {
-            float tf = dist1; dist1 = dist2; dist2 = tf;
-            uint32_t tu = nearRef; nearRef = farRef; farRef = tu;
-        }
-#endif
-#if CRT_FLAT_CF
         if (dist2 != 1e30f) {                                   // both children hit (dist1 <= dist2): push the far one
             if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
             stack.write(sp, farRef);
@@ -464,24 +407,6 @@ struct Traversal {
         }
         if (dist1 == 1e30f) pop_next(stack, c, lc);
         else ref = nearRef;
-        return;
-#endif
-        if (dist1 == 1e30f) pop_next(stack, c, lc);
-        else {
-            ref = nearRef;
-            if (dist2 != 1e30f) {
-                if (COUNT) { if (sp >= CRT_STACK_DEPTH) lc.stackOverflows++; }
-                stack.write(sp, farRef);
-                sp++;
-#ifdef CRT_PREFETCH_FAR
-                if (!(farRef & CRT_LEAF_BIT)) {      // make the pushed child's record resident before it is popped: one dword of it
-                    const float* q = reinterpret_cast<const float*>(S.pairs + (size_t)farRef * 4);
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf) : "v"(q) : "memory");
-                }
-#endif
-                if (COUNT) { if ((uint32_t)sp > lc.maxStack) lc.maxStack = (uint32_t)sp; }
-            }
-        }
     }
     // kernel_main.cl:135-140: every triangle of the leaf, then the next pop.
     // ANYHIT (shadow rays): the traversal ends at the first triangle that passes.
@@ -497,9 +422,6 @@ struct Traversal {
             inters |= intersect_triangle(mo, md, mk3(hot[0], hot[1], hot[2]), mk3(hot[3], hot[4], hot[5]), mk3(hot[6], hot[7], hot[8]), tr, i);
             if (ANYHIT) { if (inters) break; }
         }
-#ifdef CRT_PREFETCH_FAR
-        asm volatile("" : "+v"(pf));
-#endif
         if (ANYHIT && inters) finish(c);
         else pop_next(stack, c, lc);
     }
@@ -613,7 +535,7 @@ __device__ __forceinline__ void trip_steps(const CrtDevScene& S, const STK& stac
 {
     if (!done && T.at_inner()) {
         if (ITERS) { lc.rays++; if (first_active_lane()) lc.innerVisits++; }
-        T.template inner<(CRT_SCALAR_INNER >= 1)>(S, stack, c, lc);
+        T.inner(S, stack, c, lc);
     }
     if (!done && T.at_leaf()) {
         if (ITERS) {
@@ -627,7 +549,7 @@ __device__ __forceinline__ void trip_steps(const CrtDevScene& S, const STK& stac
     }
     if (!done && T.at_inner()) {
         if (ITERS) { if (first_active_lane()) lc.hits++; }
-        T.template inner<(CRT_SCALAR_INNER == 1)>(S, stack, c, lc);      // lanes that just popped an inner node go on at once
+        T.inner(S, stack, c, lc);      // lanes that just popped an inner node go on at once
     }
 }
 

@@ -182,9 +182,6 @@ void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs)
     if (S.numTexels < 1) S.numTexels = 1;
     S.numInstances = numInstances;
     S.tlas = fs.tlas; S.tlasNodes = fs.tlasNodes; S.alwaysList = fs.alwaysList; S.numAlways = fs.numAlways;
-#ifdef CRT_EXP_TOPCOUNT
-    { const char* e = getenv("CRT_EXP_TOP_PAIRS"); S.topPairs = e ? (uint32_t)atoi(e) : 0u; }
-#endif
 }
 
 // The traversal-stack overflow area of a slot must hold one block per workgroup of its largest launch.

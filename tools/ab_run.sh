@@ -2,8 +2,17 @@
 # GPU-box side of an A/B: bench every prebuilt variant under build/ab/ (tools/ab_build.sh), restoring the default library
 # afterwards (also when interrupted). BENCH_ARGS adds bench.py arguments. Usage: tools/ab_run.sh [name ...]   (default: all)
 cd "$(dirname "$0")/.."
-cp clraytracer_amd/csrc/libcrt_hip.so /tmp/libcrt_hip.default.so
-trap 'cp /tmp/libcrt_hip.default.so clraytracer_amd/csrc/libcrt_hip.so' EXIT
+# the default library waits in a file of this run's own (two A/B runs on one box, or a killed run's leftovers, cannot restore the
+# wrong one) and its hash is checked after the restore
+saved=$(mktemp /tmp/libcrt_hip.default.XXXXXX.so) || exit 1
+cp clraytracer_amd/csrc/libcrt_hip.so "$saved"
+want=$(sha256sum < "$saved")
+restore() {
+  cp "$saved" clraytracer_amd/csrc/libcrt_hip.so
+  [ "$(sha256sum < clraytracer_amd/csrc/libcrt_hip.so)" = "$want" ] || echo "WARNING: the restored libcrt_hip.so is not the library this run started with -- rebuild with make" >&2
+  rm -f "$saved" "$variant"
+}
+trap restore EXIT
 names="$@"; [ -z "$names" ] && names=$(ls build/ab)
 for name in $names; do
   [ -f build/ab/$name/libcrt_hip.so ] || { echo "[$name] no library (build failed?)" | tee -a gpurun_out/ab_results.txt; continue; }
