@@ -427,7 +427,52 @@ struct Traversal {
     }
 };
 
-// The conservative ray/sphere rejection of candidate_mask for the instance tree (same arithmetic; any NaN -> not culled).
+// ------------------------------------------------------------------------------------------------
+// The conservative instance cull, and why its slack is enough.
+//
+// Claim: if the predicate below rejects instance i for a ray (o, d), the ray fails BOTH child slab tests of that instance's
+// root as the traversal would compute them in fp32 (kernel_main.cl:203-207 transform + kernel_main.cl:108-117), so skipping the
+// instance changes no hit record; the counters add the one pop + one inner visit upstream spends on it.
+//
+// Notation. u = 2^-24, g3 = 3u/(1-3u), g4 = 4u/(1-4u). M3 / T: the 3x3 part / the translation row of the instance's fp32
+// inverseTransform, F3 = M3^-1 (double, host). kappa = |M3|_F |F3|_F (Frobenius condition number, >= 3; 3 for rigid +
+// uniform scale), tau = |T|_2 |F3|_F. (c, r): exact centre / radius of the sphere around the world image of the union of the
+// root's two child boxes; the table holds (fl(c), w) with w >= r (1 + 1e-4) + |c - fl(c)|, so its sphere contains the exact
+// one. x = |c - o|, O = |o|.
+//
+// (1) What an fp32 pass means in world space. xform_xyz sums four products left to right:
+//     |mo - o M|_2 <= g4 (|o| |M3|_F + |T|),  |md - d M3|_2 <= g3 |d| |M3|_F.
+// In a slab test every t is (b - mo_k) * (1 / md_k): three roundings, t_computed = t_exact (1 + theta), |theta| <= g3. If the
+// test passes (tnear < tfar, tnear > 0), the point p = mo + tnear md of the COMPUTED ray lies in the box grown along each
+// axis by g3 max(|bmin_k - mo_k|, |bmax_k - mo_k|) (from lo_k (1 + theta) <= tnear < hi_k (1 + theta')); a zero / overflowing
+// 1 / md_k or a 0 * inf NaN can only turn a pass into a miss or leave p inside the closed slab. Carried back to world space
+// (a factor |F3|; t is the same parameter on both sides because directions are not renormalised, H6; |d| t <= x + r there), the
+// exact world ray o + t d, t > 0, comes within
+//     Delta(O, x) = g4 (kappa O + tau) + (1 + sqrt 3) g3 kappa (x + w)
+// of the exact world image of the box, hence of the sphere (c, r): a pass implies dist(ray, c) <= r + Delta.
+// (2) What a rejection means. With fp32 inputs (fl(c), w, o, d), oc = fl(c) - o is exact to u per component, oc2, dd and b =
+// oc.d carry <= 5u, 3u (relative) and 4u |oc| |d| (absolute); `oc2 dd - b b > r2 dd` computed implies, in exact arithmetic,
+//     dist(line, fl(c))^2 > 1.0201 (1 - 12u) w^2 + (4e-6 (1 - 12u) - 19u) x^2  >=  1.02 w^2 + 2.8e-6 x^2
+// -- the 4e-6 |oc|^2 term is what outweighs the cancellation in oc2 dd - b b -- and the second clause (centre behind the origin,
+// origin outside the grown sphere) gives the same bound for every t > 0 (b < 0 computed allows b <= 4u |oc| |d| exactly, which
+// moves the closest approach by a factor 1 - 16u^2). Any NaN makes both comparisons false: not culled.
+// (3) The slack dominates when sqrt(1.02 w^2 + 2.8e-6 x^2) >= w + Delta(O, x) for all x >= 0. The left side is convex in x, the
+// right side affine; with c1 = (1 + sqrt 3) g3 kappa (4.9e-7 kappa) the minimum of the difference is at
+// 2.8e-6 x = c1 sqrt(1.02 w^2 + 2.8e-6 x^2) and equals  w (sqrt(1.02 (1 - c1^2 / 2.8e-6)) - 1 - c1) - g4 (kappa O + tau), so
+//     the cull is exact for ray origins with  |o| <= O_i = (w (sqrt(1.02 (1 - c1^2 / 2.8e-6)) - 1 - c1) - g4 tau) / (g4 kappa).
+// Rigid + uniform scale, instance centre p: kappa = 3, tau = sqrt 3 |p|: O_i ~ 13,800 w - 0.58 |p| -- a 1-unit instance may be
+// viewed from 13,800 units, a 1000-unit one from 1.4e7; kappa above ~470 (c1 > 2.3e-4) leaves no range at all.
+// (4) Outside the range the host turns the cull off (crt_shim.hip, rebuild_instance_master / render): an instance whose O_i is
+// below the reach of bounce-ray origins (object-space hit points used as world origins, H6) is stored with r = -1 = never
+// culled; a frame whose camera, or a query whose farthest origin, lies beyond the smallest O_i of the remaining instances runs
+// with an all-never table (and the linear candidate loop). tests/test_gpu_cull_bound.py: instance scales 1e-3 ... 1e3,
+// condition numbers to 300, origins out to 1e6 and to 0.95 O_i with grazing rays, hit records against the oracle.
+// (5) Nodes of the instance tree (sphere_culls on CrtTlasNode::sphere, radius R around >= 2 instance spheres, so R >= sqrt 3 w_i
+// and |C - c_i| + w_i <= R): a rejected node has dist(ray, c_i) >= dist(ray, C) - (R - w_i) > w_i + sqrt(1.02 R^2 + 2.8e-6 X^2) - R,
+// and with x_i <= X + R the same minimisation gives R (0.00995 - 2 c1) - g4 (kappa O + tau) >= the instance's own margin
+// w_i (0.00995 - c1) - ... for every c1 in the admitted range: a subtree is never rejected for a ray one of its instances admits.
+// ------------------------------------------------------------------------------------------------
+// The ray/sphere rejection of candidate_mask for the instance tree (same arithmetic; any NaN -> not culled).
 __device__ __forceinline__ bool sphere_culls(const float4 bs, v3 o, v3 d, float dd)
 {
     const v3 oc = mk3(bs.x - o.x, bs.y - o.y, bs.z - o.z);

@@ -90,6 +90,12 @@ struct State {
     float4 hBounds[CRT_MAX_INSTANCES]; CrtTlasNode hTlas[2 * CRT_MAX_INSTANCES]; uint32_t hAlways[CRT_MAX_INSTANCES];
     uint32_t hTlasNodes = 0, hNumAlways = 0; unsigned long long instVersion = 1;
     CrtBVHNode hRootNodes[CRT_MAX_MESHES]; bool hHaveRoot[CRT_MAX_MESHES];   // root node of every mesh, cached at BVH upload
+    CrtBVHNode hRootKids[CRT_MAX_MESHES][2]; bool hHaveKids[CRT_MAX_MESHES];  // ... and the root's two children: their boxes are what an entering ray is tested against
+    // Range of ray origins for which the instance cull is provably exact (derivation: crt_device.h above sphere_culls):
+    // per instance and the smallest over the cullable ones; a frame / query whose origins lie beyond it runs with `noCullBounds`.
+    float hCullOriginLimit[CRT_MAX_INSTANCES]; float cullOriginLimit = 0.0f; float bounceOriginReach = 0.0f;
+    float4* noCullBounds = nullptr;            // device: CRT_MAX_INSTANCES x (0, 0, 0, -1) = "never cull"
+    unsigned long long noCullFrames = 0;       // frames and queries that ran without the cull for that reason
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
     float* rays = nullptr;
     unsigned long long* counters = nullptr; int* err = nullptr;
@@ -174,7 +180,9 @@ void fill_frame(CrtFrame& F, const CrtTraceArgs* args, const float* invView, con
     F.rank = g.rank; F.nRanks = g.nRanks;
 }
 
-void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs)
+// noCull: the rays of this launch may start beyond the range the instance cull is proven for (State::cullOriginLimit): every
+// instance is a candidate for every ray (all-never bounds table, no instance tree)
+void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs, bool noCull = false)
 {
     S.pairs = g.pairs; S.triHot = g.triHot; S.triCold = g.triCold; S.bigLeaf = g.bigLeaf; S.rootRefs = g.rootRefs; S.stackOverflow = fs.ovf;
     S.instances = fs.instances; S.devInstances = fs.devInstances; S.instBounds = fs.instBounds; S.materials = g.materials; S.textures = g.textures; S.texels = g.texels;
@@ -182,7 +190,10 @@ void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs)
     if (S.numTexels < 1) S.numTexels = 1;
     S.numInstances = numInstances;
     S.tlas = fs.tlas; S.tlasNodes = fs.tlasNodes; S.alwaysList = fs.alwaysList; S.numAlways = fs.numAlways;
+    if (noCull) { S.instBounds = g.noCullBounds; S.tlas = nullptr; S.tlasNodes = 0; S.alwaysList = nullptr; S.numAlways = 0; g.noCullFrames++; }
 }
+// true when a ray origin this far from the world origin is outside the proven range (NaN counts as outside)
+bool beyond_cull_range(double originNorm) { return !(originNorm <= (double)g.cullOriginLimit); }
 
 // The traversal-stack overflow area of a slot must hold one block per workgroup of its largest launch.
 int ensure_overflow(FrameSlot& fs, size_t blocks)
@@ -311,6 +322,14 @@ int cache_root_nodes()
         if (g.hHaveRoot[m]) HIPCHK(hipMemcpyAsync(&g.hRootNodes[m], g.rawNodes + g.hRoots[m], sizeof(CrtBVHNode), hipMemcpyDeviceToHost, g.stream));
     }
     HIPCHK(hipStreamSynchronize(g.stream));
+    // the two children of every inner root (kernel_main.cl:144-145: leftFirst, leftFirst + 1): the cull's sphere goes around THEIR
+    // boxes, which is what the claim "a ray that misses the sphere fails both slab tests" is about -- for a tree from BuildBVH
+    // their union is the root box, for an arbitrary upload it need not be
+    for (uint32_t m = 0; m < CRT_MAX_MESHES; ++m) {
+        g.hHaveKids[m] = g.hHaveRoot[m] && g.hRootNodes[m].triCount == 0 && (unsigned long long)g.hRootNodes[m].leftFirst + 1ull < (unsigned long long)g.nodeCount;
+        if (g.hHaveKids[m]) HIPCHK(hipMemcpyAsync(&g.hRootKids[m][0], g.rawNodes + g.hRootNodes[m].leftFirst, 2 * sizeof(CrtBVHNode), hipMemcpyDeviceToHost, g.stream));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
     return CRT_OK;
 }
 
@@ -321,20 +340,43 @@ void rebuild_instance_master()
     float4* bounds = g.hBounds;
     const CrtBVHNode* rootNodes = g.hRootNodes;
     const bool* haveRoot = g.hHaveRoot;
+    // Bounce, shadow and refraction rays start at object-space hit points of the hit instance used as world-space origins
+    // (hazard H6): no farther from the world origin than the farthest corner of any mesh's root (or root children's) box, plus the
+    // 0.01 offset along the normal. An instance that cannot be culled exactly for origins that far out is never culled.
+    double reach = 0.0;
+    for (uint32_t m = 0; m < CRT_MAX_MESHES; ++m) {
+        if (!haveRoot[m]) continue;
+        const CrtBVHNode* boxes[3] = { &rootNodes[m], g.hHaveKids[m] ? &g.hRootKids[m][0] : nullptr, g.hHaveKids[m] ? &g.hRootKids[m][1] : nullptr };
+        for (const CrtBVHNode* b : boxes) {
+            if (!b) continue;
+            double far2 = 0.0;
+            for (int a = 0; a < 3; ++a) { const double v = fmax(fabs((double)b->aabbMin[a]), fabs((double)b->aabbMax[a])); far2 += v * v; }
+            const double far = sqrt(far2) * (1.0 + 1e-5) + 0.02;
+            if (far > reach || !(far == far)) reach = far;
+        }
+    }
+    g.bounceOriginReach = (float)reach;
+    double minLimit = 1e30;
+    const double U = 5.9604644775390625e-8, G3 = 3.0 * U / (1.0 - 3.0 * U), G4 = 4.0 * U / (1.0 - 4.0 * U), K = 2.8e-6;
     for (uint32_t i = 0; i < CRT_MAX_INSTANCES; ++i) {
         bounds[i] = make_float4(0.f, 0.f, 0.f, -1.0f);
+        g.hCullOriginLimit[i] = 0.0f;
         if (i >= g.instHigh) continue;
         const CrtMeshInstance& inst = g.hInstances[i];
         if (inst.meshIndex >= CRT_MAX_MESHES || !haveRoot[inst.meshIndex]) continue;
         const CrtBVHNode& root = rootNodes[inst.meshIndex];
         if (root.triCount > 0) continue;      // single-leaf mesh: its triangles are tested without any box test (hazard H3)
+        if (!g.hHaveKids[inst.meshIndex]) continue;
         double inv[16], fwd[16];
         for (int k = 0; k < 16; ++k) inv[k] = (double)(&inst.inverseTransform.m[0][0])[k];
         if (!invert4(inv, fwd)) continue;
         auto xform = [&](double x, double y, double z, double* o) {
             for (int c = 0; c < 3; ++c) o[c] = x * fwd[0 + c] + y * fwd[4 + c] + z * fwd[8 + c] + fwd[12 + c];
         };
-        const double lo[3] = { root.aabbMin[0], root.aabbMin[1], root.aabbMin[2] }, hi[3] = { root.aabbMax[0], root.aabbMax[1], root.aabbMax[2] };
+        // the box around the root's two child boxes (= the root box for a tree from BuildBVH)
+        const CrtBVHNode* kid = g.hRootKids[inst.meshIndex];
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = fmin((double)kid[0].aabbMin[a], (double)kid[1].aabbMin[a]); hi[a] = fmax((double)kid[0].aabbMax[a], (double)kid[1].aabbMax[a]); }
         double cw[3];
         xform(0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]), cw);
         double r = 0.0;
@@ -345,11 +387,25 @@ void rebuild_instance_master()
             const double dist = sqrt(dx * dx + dy * dy + dz * dz);
             if (dist > r) r = dist;
         }
-        const float rf = (float)(r * (1.0 + 1e-4)) ;
-        const float4 b = make_float4((float)cw[0], (float)cw[1], (float)cw[2], rf);
-        if (!(isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w)) || !(b.w < 1e18f)) continue;
+        // the fp32 centre the kernel reads differs from the exact one: the radius takes the difference
+        const float cf[3] = { (float)cw[0], (float)cw[1], (float)cw[2] };
+        const double ex = cw[0] - (double)cf[0], ey = cw[1] - (double)cf[1], ez = cw[2] - (double)cf[2];
+        const float rf = (float)((r * (1.0 + 1e-4) + sqrt(ex * ex + ey * ey + ez * ez)) * (1.0 + 1e-6));
+        const float4 b = make_float4(cf[0], cf[1], cf[2], rf);
+        if (!(isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w)) || !(b.w < 1e18f) || !(b.w > 1e-18f)) continue;
+        // O_i of the derivation in crt_device.h: kappa = |M3|_F |F3|_F, tau = |T| |F3|_F, c1 = (1 + sqrt 3) g3 kappa
+        double m3 = 0.0, f3 = 0.0, t2 = 0.0;
+        for (int rr = 0; rr < 3; ++rr) for (int c = 0; c < 3; ++c) { m3 += inv[rr * 4 + c] * inv[rr * 4 + c]; f3 += fwd[rr * 4 + c] * fwd[rr * 4 + c]; }
+        for (int c = 0; c < 3; ++c) t2 += inv[12 + c] * inv[12 + c];
+        const double kappa = sqrt(m3) * sqrt(f3), tau = sqrt(t2) * sqrt(f3), c1 = (1.0 + sqrt(3.0)) * G3 * kappa;
+        const double inside = 1.02 * (1.0 - c1 * c1 / K);
+        const double limit = inside > 0.0 ? ((double)rf * (sqrt(inside) - 1.0 - c1) - G4 * tau) / (G4 * kappa) : -1.0;
+        if (!(limit >= reach)) continue;      // (also NaN) never culled: bounce rays alone would leave the proven range
+        g.hCullOriginLimit[i] = (float)fmin(limit * (1.0 - 1e-6), 3e38);
+        if (limit < minLimit) minLimit = limit;
         bounds[i] = b;
     }
+    g.cullOriginLimit = (float)fmin(minLimit * (1.0 - 1e-6), 3e38);
     // Instance tree for scenes with many instances (closest_hit<..., TLAS>): median-split binary tree over the cullable
     // instances' spheres, node sphere = centre and half diagonal of the box around its children's spheres. Instances
     // that are never culled go to a separate ascending list.
@@ -380,8 +436,13 @@ void rebuild_instance_master()
                 n.pad0 = n.pad1 = 0;
                 if (r.hi - r.lo == 1) { n.sphere = bounds[leaves[r.lo]]; n.left = CRT_TLAS_LEAF | leaves[r.lo]; n.right = 0; continue; }
                 const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-                n.sphere = make_float4((float)(0.5 * (lo[0] + hi[0])), (float)(0.5 * (lo[1] + hi[1])), (float)(0.5 * (lo[2] + hi[2])),
-                                       (float)(0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-5)));
+                // (a node's sphere holds >= 2 instance spheres, so its radius is >= sqrt 3 x theirs and its share of the slack covers their
+                // Delta: crt_device.h (5); the fp32 centre's rounding goes into the radius as for the instances)
+                const double nc[3] = { 0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]) };
+                const float ncf[3] = { (float)nc[0], (float)nc[1], (float)nc[2] };
+                const double nex = nc[0] - (double)ncf[0], ney = nc[1] - (double)ncf[1], nez = nc[2] - (double)ncf[2];
+                n.sphere = make_float4(ncf[0], ncf[1], ncf[2],
+                                       (float)((0.5 * sqrt(dx * dx + dy * dy + dz * dz) * (1.0 + 1e-5) + sqrt(nex * nex + ney * ney + nez * nez)) * (1.0 + 1e-6)));
                 int axis = 0;
                 if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
                 if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
@@ -542,6 +603,12 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.counters, CRT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
     HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
+    {   // the "never cull" bounds table of frames whose rays start beyond the cull's proven range
+        static float4 never[CRT_MAX_INSTANCES];
+        for (float4& b : never) b = make_float4(0.f, 0.f, 0.f, -1.0f);
+        HIPCHK(hipMalloc(&g.noCullBounds, sizeof never));
+        HIPCHK(hipMemcpy(g.noCullBounds, never, sizeof never, hipMemcpyHostToDevice));
+    }
     g.numCUs = prop.multiProcessorCount;
     { const char* e = getenv("CRT_KERNEL"); g.wavefront = (e && strcmp(e, "wavefront") == 0); }  // default: megakernel (faster)
     { const char* e = getenv("CRT_SPLIT_BETA"); g.splitBeta = e ? (float)atof(e) : CRT_SPLIT_BETA; }
@@ -578,7 +645,7 @@ static void release_all()
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.materials, g.textures, g.rays, g.counters, g.err,
-                     g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount };
+                     g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount, g.noCullBounds };
     for (FrameSlot& fs : g.slot) {
         void* q[] = { fs.out, fs.aux, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
         for (void* p : q) if (p) (void)hipFree(p);
@@ -1003,7 +1070,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         *epilogueApplied = true;
         const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, refract = (flags & CRT_RENDER_REFRACTION) != 0;
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
-        const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh && fs.tlasNodes > 0);
+        const bool tlas = S.tlasNodes > 0 && (g.forceTlas >= 0 ? (g.forceTlas != 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh));      // (S.tlasNodes = 0: no tree, or a frame without the cull)
 #define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) crt_trace_kernel<C_, false, S_, T_, R_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters)
 #define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) CRT_LAUNCH_TRACE3(C_, S_, T_, true); else CRT_LAUNCH_TRACE3(C_, S_, T_, false); } while (0)
 #define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) CRT_LAUNCH_TRACE2(C_, S_, true); else CRT_LAUNCH_TRACE2(C_, S_, false); } while (0)
@@ -1113,7 +1180,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         if (g.wavefront) { const size_t g2 = ((size_t)F.ownedTileRows * CRT_TILE * (size_t)F.width + CRT_BLOCK - 1) / CRT_BLOCK; if (g2 > blocks) blocks = g2; }
         rc = ensure_overflow(fs, blocks); if (rc) return rc;
     }
-    fill_scene(S, args->numMeshes, fs);
+    fill_scene(S, args->numMeshes, fs, beyond_cull_range(sqrt((double)args->cameraPos[0] * args->cameraPos[0] + (double)args->cameraPos[1] * args->cameraPos[1] + (double)args->cameraPos[2] * args->cameraPos[2])));
 
     // events: [0] frame start, [1] Trace start, [2] Trace end, [3] end of PostProcess = frame end.
     // A plain frame records only two (RayGen is fused, PostProcess off): [0] == [1], [2] == [3].
@@ -1344,8 +1411,13 @@ int crt1_query_hits(const float* origins, const float* dirs, int n, uint32_t num
     FrameSlot& fs = g.slot[0];
     RCCHK(ensure_slot_instances(fs));
     RCCHK(ensure_overflow(fs, (size_t)((n + CRT_BLOCK - 1) / CRT_BLOCK)));
-    CrtDevScene S; fill_scene(S, numInstances, fs);
-    const bool tlas = g.forceTlas >= 0 ? (g.forceTlas != 0 && fs.tlasNodes > 0 && numInstances <= g.instHigh) : (numInstances > CRT_TLAS_MIN_INSTANCES && numInstances <= g.instHigh && fs.tlasNodes > 0);
+    double farthest2 = 0.0;      // the cull is proven for origins up to State::cullOriginLimit from the world origin
+    for (int k = 0; k < n; ++k) {
+        const double x = origins[3 * k], y = origins[3 * k + 1], z = origins[3 * k + 2], d2 = x * x + y * y + z * z;
+        if (!(d2 <= farthest2)) farthest2 = d2;      // (NaN sticks)
+    }
+    CrtDevScene S; fill_scene(S, numInstances, fs, beyond_cull_range(sqrt(farthest2)));
+    const bool tlas = S.tlasNodes > 0 && (g.forceTlas >= 0 ? (g.forceTlas != 0 && numInstances <= g.instHigh) : (numInstances > CRT_TLAS_MIN_INSTANCES && numInstances <= g.instHigh));
     if (tlas) crt_query_kernel<true><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
     else crt_query_kernel<false><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
     HIPCHK(hipGetLastError());
@@ -1478,6 +1550,20 @@ int crt1_get_culled_visits(uint64_t* out)
     int rc = collect_timing();
     if (rc) return rc;
     *out = g.lastCulled;
+    return CRT_OK;
+}
+
+// Diagnostic: the range of ray origins the instance cull is proven for. limits[i] = O_i of instance i (0: never culled),
+// *sceneLimit = the smallest over the cullable instances (a frame whose camera is farther out runs without the cull),
+// *bounceReach = how far from the world origin bounce-ray origins can lie, *noCullFrames = launches that ran without it so far.
+int crt1_get_cull_range(float* limits, int n, float* sceneLimit, float* bounceReach, uint64_t* noCullFrames)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (n < 0 || n > CRT_MAX_INSTANCES || (n > 0 && !limits)) return CRT_E_BAD_ARGUMENT;
+    for (int i = 0; i < n; ++i) limits[i] = g.hCullOriginLimit[i];
+    if (sceneLimit) *sceneLimit = g.cullOriginLimit;
+    if (bounceReach) *bounceReach = g.bounceOriginReach;
+    if (noCullFrames) *noCullFrames = g.noCullFrames;
     return CRT_OK;
 }
 
@@ -1830,6 +1916,7 @@ int crt_get_counters(CrtCounters* out)
     *out = total;
     return CRT_OK;
 }
+int crt_get_cull_range(float* limits, int n, float* sceneLimit, float* bounceReach, uint64_t* noCullFrames) { ON_PRIMARY(crt1_get_cull_range(limits, n, sceneLimit, bounceReach, noCullFrames)); }
 int crt_get_culled_visits(uint64_t* out)
 {
     NEED_SESSION();

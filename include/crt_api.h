@@ -190,6 +190,12 @@ int crt_get_counters(CrtCounters* out);
  * kernel_main.cl:198-217), how many the conservative instance cull answered without fetching anything: the device's
  * real child-pair fetches are innerVisits - this. (Measurement aid for bench.py's gather-rate figure.) */
 int crt_get_culled_visits(uint64_t* out);
+/* The range of ray origins for which the instance cull is provably exact (derivation: csrc/crt_device.h above sphere_culls):
+ * limits[i] (i < n <= 401) = the largest |origin| instance i may be culled for, 0 = never culled; *sceneLimit = the smallest over
+ * the cullable instances -- a crt_render whose camera, or a crt_query_hits whose farthest origin, lies beyond it runs without the
+ * cull (same results, every instance entered as upstream does, kernel_main.cl:198); *bounceReach = how far out bounce-ray origins
+ * can lie (object-space hit points, hazard H6); *noCullFrames = launches that ran without the cull so far. Any pointer may be NULL. */
+int crt_get_cull_range(float* limits, int n, float* sceneLimit, float* bounceReach, uint64_t* noCullFrames);
 /* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 8 x uint64 {start, end (s_memrealtime, 100 MHz),
  * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer loop | second-inner-step executions << 32,
  * enter-instance steps | wave-level triangle iterations << 32, first-inner-step executions, leaf steps << 32 | lane-level node

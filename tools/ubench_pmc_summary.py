@@ -29,7 +29,7 @@ if transposed:
     labels = {1: "per-lane fetch, 64 lanes", 2: "quad-transposed fetch, 64 lanes", 3: "per-lane fetch, 28 scattered lanes", 4: "quad-transposed fetch, 28 scattered lanes"}
 out = [f"# PMC passes over the chain microbenchmark (`tools/ubench/chain {'--brief-transposed' if transposed else '--brief'}`, kernel mix, 8 waves/SIMD; `tools/ubench_pmc.sh {tag}`)\n",
        "Fractions are busy cycles / (CUs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; a profiled launch runs at a lower clock than an unprofiled one.\n",
-       "| variant | kernel cycles | TA busy | TD busy | L1 pending-stall | L1 line accesses per vector load | vector loads per CU per kcycle | cycles per vector load per CU | waves parked | VALU instructions per vector load | VALU issue (4 cycles each, 4 SIMDs) |", "|---|---|---|---|---|---|---|---|---|---|---|"]
+       "| variant | kernel cycles | TA busy | TD busy | L1 pending-stall | L1 line accesses per vector load | vector loads per CU per kcycle | cycles per vector load per CU | waves parked | VALU instructions per vector load | VALU instructions x 4 cycles / (4 SIMDs x kernel cycles): >= 1 = issue-bound |", "|---|---|---|---|---|---|---|---|---|---|---|"]
 for (name, idx), c in sorted(acc.items(), key=lambda kv: kv[0][1]):
     if "GRBM_GUI_ACTIVE" not in c:
         continue
