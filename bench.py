@@ -19,24 +19,25 @@ Workload:
            round-robin to the ranks (replicated scene, no data-path collective); total work is fixed
            as N grows ("scaling": "strong"). torch.distributed (RCCL) is only used for the barrier
            and the MAX-over-ranks of the wall time.
-The N == 1 line also carries `config5_one_gpu`: the 3840x2160 frame on this one GPU (outside the timed region), the base
+The N == 1 line also carries `scale_base_n1`: the 3840x2160 frame on this one GPU (outside the timed region), the base
 of the N > 1 lines. Rays = primary rays + secondary rays actually traced, counted on the device by an instrumented
 launch outside the timed region (and checked against the oracle in tests/).
 
 The JSON line also carries
-  roofline     : the dominant kernel (crt_trace_kernel) against the ceiling that binds it -- the CU's vector-memory path
-                 serving DEPENDENT 64-B record gathers: `achieved` = real (post-cull) child-pair fetches per cycle per CU
-                 at the shader clock MEASURED beside the frames in flight (crt_debug_measure_clock), `peak` = the same
-                 figure for the chain microbenchmark at full chain occupancy and the kernel's cache-hit mix
-                 (tools/ubench/chain.hip, profiles/r*_ubench_chain.json), `frac` = achieved / peak; the same triple again as
-                 `chain`, with the ceiling at the kernel's own lane utilisation next to it. The contract's HBM roofline
-                 stays beside it: `hbm` = {achieved = PMC-measured FETCH_SIZE + WRITE_SIZE bytes per launch / device time
-                 per launch, peak = 8 TB/s, frac} (`hbm_frac`; null when no PMC profile of this workload is committed) and
-                 `traffic`. SURVEY.md 8d's layout-independent ALGORITHMIC bytes are reported as `algorithmic_*`: they
-                 exceed what reaches HBM many times over (L1/L2/Infinity Cache, the instance cull), so their rate is not
-                 a fraction of any roofline. `valu`: issue occupancy / lane utilisation / L1 accesses from the PMC passes.
-  with_shadow_rays / dense_view / reference_assets : BASELINE configs 3-4 as written (primary + 1 shadow ray), the dense view
-                 of the same scene, and upstream's own Sponza + Sibenik assets -- each outside the contract's timed region.
+  roofline     : the contract's HBM roofline of the dominant kernel (crt_trace_kernel): `bound` "hbm", `achieved` = bytes that really
+                 leave L2 per launch (`traffic`: FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command,
+                 `traffic_source`; null when no profile of this workload is committed) / the device time per launch measured
+                 live with HIP events on the launch streams, `peak` = 8 TB/s, `frac` = achieved / peak (never printed above 1).
+                 SURVEY.md 8d's layout-independent ALGORITHMIC bytes are `algorithmic_*`: they exceed what reaches HBM 30x over
+                 (L1/L2/Infinity Cache, the instance cull), so `algorithmic_over_hbm_peak` (> 1) is a work measure, not a
+                 fraction of any roofline (`frac_definition` says so in the line). Secondary ceilings from the same PMC passes:
+                 `l2` (TCP_TCC_READ_REQ x 64 B / device time against 34.5 TB/s), `l1_hit`, `l2_hit`, `lds_instructions_per_launch`.
+                 `chain` = a MODEL, not a bound, and only for the workload it was calibrated on (multi-1M, default size): real
+                 (post-cull) child-pair fetches per cycle per CU against the dependent-gather microbenchmark at the kernel's
+                 cache-hit mix (tools/ubench/chain.hip, profiles/r*_ubench_chain.json). `valu` / `vmem_pipe`: issue-side accounting.
+  with_shadow_rays / dense_view / reference_assets / wavefront_compaction : BASELINE configs 3-4 as written (primary + 1 shadow
+                 ray; "wavefront compaction on" = the CRT_KERNEL=wavefront form), the dense view of the same scene, and upstream's own
+                 Sponza + Sibenik assets -- each outside the contract's timed region.
   cpu_baseline : the reference's CPU path timed on this box's host cores (rank 0, N == 1 only): the mirrored
                  CPU_RayCast (CPURayTrace.cpp:186-249, SSE flavour with upstream's rcpps/dpps instruction mix) over the
                  primary rays of the bench frame at 1 thread and at all usable cores, and the scalar Trace oracle
@@ -201,6 +202,48 @@ def pmc_vmem(kernel, workload_scene, width, height, dev_s, clock_ghz, num_cus):
         except Exception:
             continue
     return None
+
+
+def pmc_summary(kernel, workload_scene, width, height):
+    """The newest committed rocprofv3 summary (profiles/r*_summary.json, tools/profile_summary.py) of `kernel` on this workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            b = d.get("bench_line") or {}
+            if d.get("kernel", "").startswith(kernel.split("<")[0]) and b.get("config", {}).get("scene") == workload_scene and not b["config"].get("diag_mix3") \
+                    and b["config"].get("width") == width and b["config"].get("height") == height and d.get("counters"):
+                return d, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2 read bandwidth
+
+
+def secondary_ceilings(kernel, workload_scene, width, height, dev_s):
+    """SURVEY.md 8d's secondary ceilings from the committed PMC passes: L2 request bytes over THIS run's device time per launch
+    against the guide's aggregate L2 bandwidth, the L1 / L2 hit rates, LDS instructions per launch (the traversal stack)."""
+    d, src = pmc_summary(kernel, workload_scene, width, height)
+    if d is None:
+        return None
+    c, dv = d["counters"], d.get("derived", {})
+    out = {"source": src}
+    if "TCP_TCC_READ_REQ_sum" in c:
+        req = c["TCP_TCC_READ_REQ_sum"]["mean_per_launch"]
+        gbs = req * 64.0 / dev_s / 1e9
+        out["l2"] = {"achieved": round(gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_PEAK_GBS, 4),
+                     "achieved_definition": "TCP_TCC_READ_REQ (L1 -> L2 read requests per launch) x 64 B / device time per launch of this run"}
+    if "l1_hit_rate" in dv:
+        out["l1_hit"] = round(dv["l1_hit_rate"], 4)
+    if "l2_hit_rate" in dv:
+        out["l2_hit"] = round(dv["l2_hit_rate"], 4)
+    if "SQ_INSTS_LDS" in c:
+        out["lds_instructions_per_launch"] = int(c["SQ_INSTS_LDS"]["mean_per_launch"])
+        out["lds_note"] = "wave-level LDS instructions (traversal-stack pushes / pops, parked values); SQ_LDS_BANK_CONFLICT = %s" % (
+            int(c["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"]) if "SQ_LDS_BANK_CONFLICT" in c else "n/a")
+    return out
 
 
 def pmc_traffic(kernel, workload_scene, width, height):
@@ -529,6 +572,18 @@ def main():
         _, deliver_elapsed, _ = aggregate(dist, cnt, own_rows * width, deliver_elapsed, 0.0, red_device, ctl)
         _, deliver8_elapsed, _ = aggregate(dist, cnt, own_rows * width, deliver8_elapsed, 0.0, red_device, ctl)
 
+    staggered_frames = 0
+    if rank == 0:
+        v_ = C.c_uint64()
+        if hip.crt_debug_staggered_frames(C.byref(v_)) == 0:
+            staggered_frames = int(v_.value)
+    # per-rank times of the timed region (N > 1): who was slowest, and by how much
+    rank_ms = [elapsed * 1e3 / args.steps]
+    if dist is not None and not inproc:
+        tv = torch.zeros(n, dtype=torch.float64, device=red_device)
+        tv[rank] = elapsed * 1e3 / args.steps
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM, group=ctl)
+        rank_ms = [float(x) for x in tv.tolist()]
     if rank == 0:
         rays_per_frame = tot["rays"]
         ms_per_step = elapsed_max * 1e3 / args.steps
@@ -549,13 +604,21 @@ def main():
         ndev_here = n if inproc else 1                                          # in-process: counters are summed over the devices
         gather_rate = pair_fetches / ndev_here / (dev_s * clock_ghz * 1e9 * num_cus)   # 64-B records per cycle per CU
         warnings = []
+        roofline_error = None
         if hbm_frac is not None and hbm_frac > 1.0:
-            warnings.append(f"measured HBM traffic rate {hbm_achieved:.0f} GB/s exceeds the peak: the committed profile does not belong to this build")
-        ceil = chain_ceiling()
+            # a true bound cannot be exceeded: the committed profile does not belong to this build / workload -> no fraction is printed
+            roofline_error = f"measured HBM traffic {traffic} B per launch over {dev_s * 1e3:.4f} ms = {hbm_achieved:.0f} GB/s exceeds the {HBM_PEAK_GBS:.0f} GB/s peak: stale profile ({traffic_src})"
+            warnings.append(roofline_error)
+            hbm_achieved = hbm_frac = None
+        second = secondary_ceilings("crt_trace_kernel", sc.name, width, height, dev_s) if (n == 1 and not args.shadows) else None
+        # the chain microbenchmark's table reproduces multi-1M's cache-hit mix at the default frame size: a model for that workload only
+        chain_applies = n == 1 and sc.name == "multi-1M" and (width, height) == (1920, 1080) and not args.shadows and not args.diag_mix3
+        ceil = chain_ceiling() if chain_applies else None
         chain = None
         if ceil:
-            chain = {"achieved": round(gather_rate, 4), "ceiling": round(ceil["full"], 4), "frac": round(gather_rate / ceil["full"], 4),
-                     "unit": "64-B records per cycle per CU",
+            chain = {"kind": "model: a microbenchmark's rate at this workload's cache-hit mix, not a bound (coherent packets can exceed it)",
+                     "achieved": round(gather_rate, 4), "ceiling": round(ceil["full"], 4), "frac": round(gather_rate / ceil["full"], 4),
+                     "unit": "64-B records per cycle per CU", "calibrated_for": "multi-1M 1920x1080, primary + reflection bounce",
                      "ceiling_at_28_of_64_lanes": None if ceil["lanes28"] is None else round(ceil["lanes28"], 4),
                      "frac_of_ceiling_at_28_lanes": None if ceil["lanes28"] is None else round(gather_rate / ceil["lanes28"], 4),
                      "ceiling_source": ceil["source"], "clock_ghz": round(clock_ghz, 4), "clock_source": clock_src, "cus": num_cus,
@@ -564,8 +627,6 @@ def main():
                              "Infinity Cache); the same rate from 2 to 8 waves/SIMD, i.e. a throughput limit of the CU's vector-memory path, not latency. The "
                              "trace kernel runs with ~28 of 64 lanes working per vector instruction (ceiling_at_28_of_64_lanes) and its packets are partly "
                              "coherent (several lanes per record), which is how it can sit above that second figure"}
-            if chain["frac"] > 1.0:
-                warnings.append("gather rate above the chain microbenchmark's ceiling: coherent packets fetch several lanes per record; see chain.note")
         out = {
             "metric": "Mrays/s (primary + traced secondary rays), ms/frame at 1920x1080" if n == 1 else "Mrays/s (primary + traced secondary rays), 3840x2160 tiled over N GPUs",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -580,6 +641,11 @@ def main():
                                   "every frame gathered into device 0 by peer copies inside the timed region") if inproc
                                  else f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
                        "frames_in_flight": flight, "control_plane": control_plane, "diag_mix3": bool(args.diag_mix3), "prewarm_ms": args.prewarm_ms,
+                       "stagger": {"mode": ("CRT_STAGGER_US=" + os.environ["CRT_STAGGER_US"]) if "CRT_STAGGER_US" in os.environ
+                                           else "automatic: the first frame of slots 1.. of a burst that follows a burst longer than the slot count is held back by slot x latency / slots (up to 3 slots)",
+                                   "frames_held_back_in_session": staggered_frames},
+                       "n_gt_1_lines": "lines with n_gpus > 1 render BASELINE config 5 (3840x2160), not this 1920x1080 frame: their base is `scale_base_n1` here / "
+                                       "`single_gpu_same_workload` there, never this line's `value`" if n == 1 else None,
                        "device": hip.crt_device_name().decode(), "scene_load_s": round(t_load, 2),
                        "scene_load": ("max over ranks; meshes from the .clm caches rank 0 wrote once, BVH built on each GPU (crt_build_bvh)" if n > 1
                                       else "OBJ import (or .clm cache) + host SAH build + uploads")},
@@ -592,22 +658,29 @@ def main():
             "kernel_ms": {"crt_trace_kernel_launch_mean": round(launch_ms, 4), "device_time_per_frame": round(extent_ms, 4),
                           "frame_latency_mean": round(stats.sumMs[0] / max(1, stats.frames), 4),
                           "device_time_per_frame_max_over_ranks": round(kernel_ms_max, 4)},
-            "roofline": {"bound": "dependent 64-B gathers through the CU's vector-memory path (not HBM: see hbm_frac)",
-                         "achieved": None if chain is None else chain["achieved"], "peak": None if chain is None else chain["ceiling"],
-                         "unit": "64-B records per cycle per CU", "frac": None if chain is None else chain["frac"],
-                         "chain": chain,
-                         "hbm": {"achieved": None if hbm_achieved is None else round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": None if hbm_frac is None else round(hbm_frac, 4),
-                                 "achieved_definition": "PMC-measured FETCH_SIZE + WRITE_SIZE bytes per launch / device time per launch"},
-                         "hbm_frac": None if hbm_frac is None else round(hbm_frac, 4),
+            "roofline": {"bound": "hbm",
+                         "achieved": None if hbm_achieved is None else round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if hbm_frac is None else round(hbm_frac, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_definition": "achieved / peak with achieved = `traffic` (FETCH_SIZE + WRITE_SIZE bytes per launch from the committed rocprofv3 --pmc passes of this "
+                                            "command: every byte that leaves L2, Infinity-Cache hits included, so an upper bound on HBM bytes) / device_time_per_launch_ms "
+                                            "(HIP events on the launch streams, this run). HBM is NOT what binds this kernel (dependent 64-B gathers through the CU's "
+                                            "vector-memory path are: see `chain`, a model); SURVEY 8d's algorithmic bytes are a work measure (algorithmic_over_hbm_peak > 1)",
+                         "error": roofline_error,
+                         "hbm_frac": None if hbm_frac is None else round(hbm_frac, 4),
+                         "l2": None if not second else second.get("l2"), "l1_hit": None if not second else second.get("l1_hit"),
+                         "l2_hit": None if not second else second.get("l2_hit"),
+                         "lds_instructions_per_launch": None if not second else second.get("lds_instructions_per_launch"),
+                         "secondary_source": None if not second else second.get("source"),
+                         "chain": chain,
                          "kernel": "crt_trace_kernel<COUNT=false, STAMP=false, SHADOW=%s, TLAS=false, REFRACT=false>" % ("true" if args.shadows else "false"),
                          "launch_duration_ms": round(launch_ms, 4), "launches_in_flight": flight, "device_time_per_launch_ms": round(extent_ms, 4),
                          "algorithmic_bytes_per_launch": int(my_bytes),
                          "algorithmic_rate_gbs": round(my_bytes / dev_s / 1e9, 2),
+                         "algorithmic_over_hbm_peak": round(my_bytes / dev_s / 1e9 / HBM_PEAK_GBS, 3),
                          "algorithmic_over_traffic": None if traffic is None else round(my_bytes / traffic, 1),
                          "algorithmic_note": "SURVEY 8d bytes from reference struct sizes; served from L1/L2/Infinity Cache and removed by the instance cull, "
-                                             "hence far above the HBM traffic and not a fraction of the HBM roofline",
+                                             "hence far above the HBM traffic: algorithmic_over_hbm_peak is a work measure, NOT a roofline fraction",
                          "bytes_per_ray": round(my_bytes / max(1, cnt["rays"]), 1),
                          "inner_visits_per_ray": round(cnt["innerVisits"] / max(1, cnt["rays"]), 2),
                          "tri_tests_per_ray": round(cnt["triTests"] / max(1, cnt["rays"]), 2),
@@ -638,6 +711,13 @@ def main():
         if single is not None:
             out["single_gpu_same_workload"] = {"value": round(rays_per_frame / single / 1e6, 2), "unit": "Mrays/s",
                                                "ms_per_step": round(single * 1e3, 4), "note": "rank 0 alone rendering the whole frame, 10 frames, same mode"}
+            out["speedup_vs_single_gpu_same_workload"] = round(value / (rays_per_frame / single / 1e6), 3)
+        if n > 1:
+            out["per_rank_ms_per_step"] = [round(x, 4) for x in rank_ms]
+            out["imbalance_max_over_mean"] = round(max(rank_ms) / (sum(rank_ms) / len(rank_ms)), 4) if not inproc else None
+            out["scaling_note"] = ("speedup_vs_single_gpu_same_workload = value / single_gpu_same_workload.value (the same 3840x2160 frame on one GPU, measured in this run); "
+                                   "do not divide by the n_gpus = 1 line's value, which is the 1920x1080 frame. No 1 -> 8 GPU curve had been measured on hardware when this was written."
+                                   + (" REHEARSAL: every rank shares GPU 0, the numbers are meaningless." if rehearse else ""))
         extras = n == 1 and not args.no_extras and not args.width and not args.height and args.scene == "multi-1M" and not args.shadows
         kx = max(20, min(100, args.steps))
         if extras:
@@ -673,9 +753,10 @@ def main():
             _lib.check(hip.crt_sync(), "crt_sync")
             dt5 = (time.perf_counter() - t0) / k5
             _lib.check(rc, "crt_render")
-            out["config5_one_gpu"] = {"value": round(rays5 / dt5 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt5 * 1e3, 4),
-                                      "rays_per_frame": rays5, "frames": k5,
-                                      "note": "the same scene at 3840x2160 on this one GPU (BASELINE config 5 at N = 1): the base of the N > 1 lines"}
+            out["scale_base_n1"] = {"value": round(rays5 / dt5 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt5 * 1e3, 4),
+                                    "rays_per_frame": rays5, "frames": k5, "workload": f"{sc.name} 3840x2160 (BASELINE config 5) on one GPU",
+                                    "note": "the N = 1 point of the scaling curve: lines with n_gpus > 1 render THIS frame tiled over the ranks (they carry the same "
+                                            "measurement as single_gpu_same_workload); formerly `config5_one_gpu`"}
             s.resize(width, height)
         if extras:
             # upstream's own assets (Sponza + Sibenik .clm caches with their 27 JPEG texture imports) and BASELINE config 3
@@ -695,6 +776,18 @@ def main():
                     if tr2:
                         out[key]["hbm"] = {"traffic": tr2, "traffic_source": src2, "achieved_gbs": round(tr2 / (out[key]["steady_state"]["ms_per_step"] * 1e-3) / 1e9, 1),
                                            "frac": round(tr2 / (out[key]["steady_state"]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # BASELINE config 4 as written ("LDS stack + wavefront compaction on"): the wavefront form of Trace -- bounce 0, ballot compaction of
+            # the continuing paths into a queue, bounce 1 as dense 64-ray packets (CRT_KERNEL=wavefront, read by crt_init) -- on the bench frame.
+            # Bit-identical to the default kernel and to the oracle at this size (tests/test_gpu_variants.py); slower, which is why it is opt-in.
+            os.environ["CRT_KERNEL"] = "wavefront"
+            try:
+                with driver.Session(width, height, device=device_index) as sw:
+                    sw.load_scene(sc)
+                    out["wavefront_compaction"] = measure_view(sw, flags, kx, f"{sc.name} {width}x{height}, primary + reflection bounce, crt_primary_kernel -> compaction -> crt_bounce_kernel")
+                    out["wavefront_compaction"]["synchronous_frames"] = measure_view(sw, flags & ~4, kx, "same frame, one at a time")["value"]
+                    out["wavefront_compaction"]["vs_default_kernel"] = round(out["wavefront_compaction"]["value"] / value, 3)
+            finally:
+                del os.environ["CRT_KERNEL"]
             s = driver.Session(width, height, device=device_index)
             s.load_scene(sc)
         if n == 1 and not args.no_cpu_baseline:

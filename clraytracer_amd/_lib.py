@@ -64,6 +64,7 @@ HIP_API = {
     "crt_peer_access": (C.c_int, [C.c_int]),
     "crt_gather_path": (C.c_char_p, []),
     "crt_get_cull_range": (C.c_int, [_fp, C.c_int, _fp, _fp, C.POINTER(C.c_uint64)]),
+    "crt_debug_staggered_frames": (C.c_int, [C.POINTER(C.c_uint64)]),
     "crt_debug_inject_failure": (C.c_int, [C.c_int]),
     "crt_debug_measure_clock": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "crt_shutdown": (C.c_int, []),

@@ -78,6 +78,9 @@ struct State {
     // idle is therefore held back on its stream by slot x (last frame latency / slots) by a one-wave timer kernel.
     float pipelinedLatencyMs = 0.0f;     // latency of the newest plain frame-in-flight timed so far (what the stagger is derived from; 0 = none yet)
     unsigned burstFrames = 0; int staggerUs = -1;   // frames submitted since the device was last known idle; CRT_STAGGER_US: -1 = automatic, 0 = off, n = n us per slot
+    // Automatic = only for a caller that is known to stream: the burst before this one ran longer than the slot count. A caller that
+    // submits two or three frames and then reads never reaches steady state and would only pay the hold-back as latency.
+    unsigned prevBurstFrames = 0; unsigned long long staggeredFrames = 0;
     int width = 0, height = 0;
     int bandRows = 16, rank = 0, nRanks = 1;
     // raw (reference-layout) device copies
@@ -147,6 +150,7 @@ int sync_all()
 {
     HIPCHK(hipStreamSynchronize(g.slot[0].stream));
     RCCHK(quiesce());
+    if (g.burstFrames) g.prevBurstFrames = g.burstFrames;
     g.burstFrames = 0;                          // every slot is idle: the next pipelined frames start a burst
     return CRT_OK;
 }
@@ -1193,13 +1197,13 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         const unsigned k = g.burstFrames++;
         // (automatic only with up to three slots: with eight -- a rank's small share of a tiled frame, where one frame cannot fill the
         // GPU and the slots exist to run many at once -- the ramp costs more than the coinciding tails: 83.2 -> 74.6 Gray/s predicted at N = 8)
-        if (k > 0 && k < (unsigned)g.nSlots && g.staggerUs != 0 && (g.staggerUs > 0 || g.nSlots <= 3)) {
+        if (k > 0 && k < (unsigned)g.nSlots && g.staggerUs != 0 && (g.staggerUs > 0 || (g.nSlots <= 3 && g.prevBurstFrames > (unsigned)g.nSlots))) {
             double step = g.staggerUs > 0 ? (double)g.staggerUs : (double)g.pipelinedLatencyMs * 1e3 / (double)g.nSlots;
             if (step > 500.0) step = 500.0;                      // a stale or foreign latency must not stall a burst
             const double us = step * k;
-            if (us >= 5.0) { crt_delay_kernel<<<1, 64, 0, fs.stream>>>((unsigned long long)(us * 100.0)); HIPCHK(hipGetLastError()); }
+            if (us >= 5.0) { crt_delay_kernel<<<1, 64, 0, fs.stream>>>((unsigned long long)(us * 100.0)); HIPCHK(hipGetLastError()); g.staggeredFrames++; }
         }
-    } else g.burstFrames = 0;
+    } else { if (g.burstFrames) g.prevBurstFrames = g.burstFrames; g.burstFrames = 0; }
     es.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
     es.evPost = (flags & (CRT_RENDER_POSTPROCESS | CRT_RENDER_UNORM8 | CRT_RENDER_FXAA)) != 0;
     HIPCHK(hipEventRecord(es.ev[0], fs.stream));
@@ -1790,7 +1794,16 @@ const char* crt_gather_path(void)
     for (int d = 1; d < M.n; ++d) if (M.peer[d] < lo) lo = M.peer[d];
     return lo == 2 ? "same-device copies (rehearsal: one GPU listed several times)" : (lo == 1 ? "xgmi-peer" : "host-staged");
 }
-int crt_debug_inject_failure(int device) { NEED_SESSION(); if (device < 0 || device >= M.n) return CRT_E_BAD_ARGUMENT; M.injectFailure = device; return CRT_OK; }
+// armed only in a process that asked for the test hooks (CRT_DEBUG_HOOKS=1): a production caller cannot make a frame fail by accident
+int crt_debug_inject_failure(int device)
+{
+    NEED_SESSION();
+    { const char* e = getenv("CRT_DEBUG_HOOKS"); if (!e || atoi(e) == 0) return CRT_E_UNSUPPORTED; }
+    if (device < 0 || device >= M.n) return CRT_E_BAD_ARGUMENT;
+    M.injectFailure = device;
+    return CRT_OK;
+}
+int crt_debug_staggered_frames(uint64_t* out) { NEED_SESSION(); if (!out) return CRT_E_BAD_ARGUMENT; Use u_(0); *out = g.staggeredFrames; return CRT_OK; }
 int crt_debug_measure_clock(int micros, double* ghz) { ON_PRIMARY(crt1_debug_measure_clock(micros, ghz)); }
 
 int crt_shutdown(void)

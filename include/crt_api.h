@@ -209,8 +209,13 @@ int crt_debug_read_frame_times(double* dst, size_t maxFrames, size_t* numFrames)
  * beside frames in flight so that cycle-based figures use the measured clock, not the 2.4 GHz nominal one). */
 int crt_debug_measure_clock(int micros, double* ghz);
 /* Test hook (multi-device sessions): the next crt_render / crt_resize fails on session device `device` as if that
- * device's submission had returned an error, once. Exercises the "a secondary failed" paths of the dispatcher. */
+ * device's submission had returned an error, once. Exercises the "a secondary failed" paths of the dispatcher. Refused with
+ * CRT_E_UNSUPPORTED unless the process runs with CRT_DEBUG_HOOKS=1 in its environment. */
 int crt_debug_inject_failure(int device);
+/* Diagnostic: frames of this session that were held back by the start-up stagger of a burst of CRT_RENDER_ASYNC frames (a
+ * caller that streams -- the burst before ran longer than the frame-slot count -- has the first frame of slots 1.. of a new burst
+ * delayed by slot x latency / slots so that the slots do not run in lockstep; CRT_STAGGER_US=0 turns it off, =n forces n us). */
+int crt_debug_staggered_frames(uint64_t* out);
 
 const char* crt_error_string(int code);
 const char* crt_device_name(void);

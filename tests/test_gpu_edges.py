@@ -227,6 +227,64 @@ def test_frames_in_flight_match_synchronous_frames(nthreads, monkeypatch, slots)
         assert np.array_equal(bits(s.read_output()), bits(ref1))
 
 
+def test_short_bursts_are_never_held_back(monkeypatch):
+    """The start-up stagger (crt_shim.hip, State::burstFrames) holds back the first frame of slots 1.. when a burst of frames in
+    flight starts on an idle device -- for a caller that STREAMS. A caller that submits two or three ASYNC frames and then reads
+    would only pay it as latency: such bursts must never be held back. crt_debug_staggered_frames counts the delay
+    launches, so the rule is checked exactly; the burst latency with the stagger on and forced off is printed and loosely bounded."""
+    import time
+    monkeypatch.delenv("CRT_STAGGER_US", raising=False)
+    monkeypatch.setenv("CRT_FRAMES_IN_FLIGHT", "3")
+    sc = scenes.get("cornell-1k")
+    ASYNC = 4
+    hip = _lib.hip()
+
+    def staggered():
+        v = C.c_uint64()
+        assert hip.crt_debug_staggered_frames(C.byref(v)) == 0
+        return int(v.value)
+
+    def short_bursts(s, n=40):
+        lat = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            for _ in range(3):
+                s.render_raw(ASYNC)
+            s.sync()
+            lat.append(time.perf_counter() - t0)
+        return float(np.median(lat)) * 1e3
+
+    with driver.Session(1920, 1080, device=0) as s:
+        s.load_scene(sc)
+        s.render_raw(0); ref = s.read_output().copy()
+        on = short_bursts(s)
+        assert staggered() == 0                                        # nothing but 3-frame bursts so far: never held back
+        for _ in range(12):
+            s.render_raw(ASYNC)                                        # a streaming caller: a burst longer than the slot count ...
+        s.sync()
+        assert staggered() == 0                                        # ... (itself started like any first burst) ...
+        for _ in range(12):
+            s.render_raw(ASYNC)
+        assert np.array_equal(bits(s.read_output()), bits(ref))
+        assert staggered() == 2                                        # ... makes the NEXT burst start staggered: slots 1 and 2 once
+        short_bursts(s, 3)                                             # the burst before was long: this one is staggered, the following are not
+        assert staggered() == 4
+    monkeypatch.setenv("CRT_STAGGER_US", "0")
+    with driver.Session(1920, 1080, device=0) as s:
+        s.load_scene(sc)
+        s.render_raw(0)
+        off = short_bursts(s)
+        for _ in range(12):
+            s.render_raw(ASYNC)
+        s.sync()
+        for _ in range(12):
+            s.render_raw(ASYNC)
+        s.sync()
+        assert staggered() == 0
+    print(f"3-frame burst + sync, cornell-1k 1920x1080: {on:.3f} ms with the automatic stagger, {off:.3f} ms with CRT_STAGGER_US=0")
+    assert on <= 1.25 * off + 0.05
+
+
 def test_empty_inputs(nthreads):
     """No instances: every ray misses and samples the skybox (kernel_main.cl:198 loops zero times); zero query rays; a
     zero-byte upload; a frame of the minimum size."""

@@ -152,7 +152,7 @@ def test_peer_access_state_is_reported():
 
 
 @pytest.mark.parametrize("flags", [0, 4])
-def test_a_failing_secondary_fails_the_frame_and_the_session_recovers(flags):
+def test_a_failing_secondary_fails_the_frame_and_the_session_recovers(flags, monkeypatch):
     """If a secondary device's submission fails, crt_render returns the error WITHOUT queueing the primary's wait for that
     device's bands (it would otherwise wait on the slot's previous frame's event and present stale bands as a finished
     frame). The slot rotation advances on every device alike, so the following frames are whole and correct again."""
@@ -164,6 +164,10 @@ def test_a_failing_secondary_fails_the_frame_and_the_session_recovers(flags):
         s.load_scene(sc)
         for _ in range(4):
             assert _render(s, flags) == 0
+        monkeypatch.delenv("CRT_DEBUG_HOOKS", raising=False)
+        assert hip.crt_debug_inject_failure(1) == -5          # CRT_E_UNSUPPORTED: the hook is dead in a process that did not ask for it
+        assert _render(s, flags) == 0
+        monkeypatch.setenv("CRT_DEBUG_HOOKS", "1")
         for bad in (1, 2, 0):
             assert hip.crt_debug_inject_failure(bad) == 0
             assert _render(s, flags) != 0                      # the frame is abandoned, the error reported
@@ -173,7 +177,7 @@ def test_a_failing_secondary_fails_the_frame_and_the_session_recovers(flags):
         assert hip.crt_debug_inject_failure(7) != 0
 
 
-def test_failed_resize_rolls_every_device_back():
+def test_failed_resize_rolls_every_device_back(monkeypatch):
     """crt_resize on a session is all-or-nothing: when one device cannot reallocate, the devices that already did go back to
     the old size, the error is returned and the session keeps rendering the old frame size."""
     sc = scenes.get("tiny")
@@ -182,6 +186,7 @@ def test_failed_resize_rolls_every_device_back():
     hip = _lib.hip()
     with driver.Session(w, h, devices=[0, 0, 0]) as s:
         s.load_scene(sc)
+        monkeypatch.setenv("CRT_DEBUG_HOOKS", "1")
         assert hip.crt_debug_inject_failure(2) == 0
         with pytest.raises(driver.CrtError):
             s.resize(640, 360)                                 # Renderer::OnWindowResize -> crt_resize fails on device 2

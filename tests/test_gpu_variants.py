@@ -42,6 +42,35 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     assert not np.array_equal(bits(fused[0]), bits(ref)) and not np.array_equal(bits(fused[2]), bits(fused[0]))
 
 
+def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkeypatch):
+    """BASELINE config 4 as written ("LDS stack + wavefront compaction on"): multi-1M, 1920x1080, rendered by the wavefront form
+    (crt_primary_kernel -> ballot compaction -> crt_bounce_kernel; the bounce loop of kernel_main.cl:187 split into launches)
+    and compared with the ORACLE -- frame bits and every work counter -- and with the oracle-written known answer
+    tests/golden/full_frames.json; synchronous, with frames in flight, and with the shadow-ray-free flags the variant supports."""
+    import hashlib, json, os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_frames.json")))["multi-1M"]
+    import oracle_lib
+    sc = scenes.get("multi-1M")
+    monkeypatch.setenv("CRT_KERNEL", "wavefront")
+    with driver.Session(1920, 1080, device=0) as s:
+        s.load_scene(sc)
+        orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
+        iv, ip, pos = s.camera()
+        ref, st = orc.trace(orc.raygen(1920, 1080, iv, ip), pos, sc.sun_angle)
+        s.render_raw(FLAG_COUNT)
+        got = s.read_output(); cnt = s.counters()
+        assert cnt == st                                                   # rays, hits, pops, inner visits, triangle tests, max stack ...
+        assert np.array_equal(bits(got[..., :3]), bits(ref[..., :3]))
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == gold["frame_sha256"]
+        assert {k: cnt[k] for k in gold["counters"]} == gold["counters"]
+        s.render_raw(0)
+        assert np.array_equal(bits(s.read_output()), bits(got))
+        for _ in range(5):
+            s.render_raw(4)                                                # frames in flight
+        assert np.array_equal(bits(s.read_output()), bits(got))
+        print(f"wavefront multi-1M 1920x1080: {st['rays']} rays, {st['secondary']} compacted bounce rays, frame and counters equal to the oracle")
+
+
 def test_stamped_launch_renders_the_same_frame():
     """CRT_RENDER_STAMPS (the diagnostic instantiation behind tools/wave_timeline.py: per-wave start/end stamps, 6 waves per
     SIMD) must render the frame the plain launch renders -- also through the per-pixel epilogue (PostProcess, RGBA8 target),
