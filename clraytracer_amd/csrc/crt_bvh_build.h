@@ -912,7 +912,7 @@ __global__ void __launch_bounds__(CRT_BVH_SCAN_THREADS) crt_bvh_scan_apply(const
 
 // every build node gets its final index and is written out as a reference-layout BVHNode; roots[m] and the node count too
 __global__ void crt_bvh_emit(const CrtBuildNode* __restrict__ nodes, uint32_t count, int numMeshes, const uint32_t* __restrict__ S, uint32_t poolFirst, uint32_t poolCount,
-                             uint32_t firstNode, CrtBVHNode* __restrict__ out, uint32_t* __restrict__ roots, uint32_t* __restrict__ nodesUsed)
+                             uint32_t firstNode, CrtBVHNode* __restrict__ out, uint32_t* __restrict__ roots, uint32_t* __restrict__ nodesUsed, uint32_t* __restrict__ outOfRange)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= count) return;
@@ -928,6 +928,9 @@ __global__ void crt_bvh_emit(const CrtBuildNode* __restrict__ nodes, uint32_t co
     for (int c = 0; c < 3; ++c) { o.aabbMin[c] = n.bmin[c]; o.aabbMax[c] = n.bmax[c]; }
     if (n.left == CRT_BVH_NONE) { o.leftFirst = n.first; o.triCount = n.count; }
     else { o.leftFirst = base; o.triCount = 0; }
+    // the closed form is trusted only as far as the node array it was sized for: a number outside [firstNode, firstNode + count) would mean
+    // a damaged tree, and is reported instead of stored (the host then refuses the build)
+    if (index - firstNode >= count) { atomicOr(outOfRange, 1u); return; }
     out[index] = o;
     if (n.depth == 0) roots[n.mesh] = rootIndex;
     if (k == 0) *nodesUsed = 2u * S[poolCount] - (uint32_t)numMeshes;

@@ -810,6 +810,10 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     if (firstTri + total > 0x00FFFFFFu) return CRT_E_OUT_OF_RANGE;                 // leaf references carry 24-bit triangle indices
     if (firstNode + 2 * total > g.nodeCap) return CRT_E_OUT_OF_RANGE;              // a mesh of n triangles needs at most 2n-1 nodes
     if (total / CRT_BVH_SMALL >= 4096 || total / CRT_BVH_TINY >= (1u << 20)) return CRT_E_OUT_OF_RANGE;   // field widths of the packed per-level counter (crt_bvh_build.h)
+    {   // test hook (CRT_DEBUG_HOOKS=1 only): refuse, so that the caller's fall-back to the host BuildBVH can be exercised
+        const char* h = getenv("CRT_DEBUG_HOOKS"); const char* f = getenv("CRT_DEBUG_FAIL_BVH_BUILD");
+        if (h && atoi(h) != 0 && f && atoi(f) != 0) return CRT_E_OUT_OF_RANGE;
+    }
     RCCHK(sync_all());
 
     // second triangle pool (allocated on first use, indexed like rawTris) and scratch:
@@ -911,35 +915,37 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         for (int c = 0; c < 3; ++c) cnt[c] = bvh_unpack(ctl.packed, c);
         chunks = ctl.nextChunks;
         const uint32_t newEnd = end + cnt[0] + cnt[1] + cnt[2];
-        if (newEnd > (uint32_t)maxNodes || cnt[0] > maxBig || chunks > maxChunks) return CRT_E_OUT_OF_RANGE;
+        if (newEnd > (uint32_t)maxNodes || cnt[0] > maxBig || chunks > maxChunks) { (void)hipStreamSynchronize(st); return CRT_E_OUT_OF_RANGE; }   // nothing stays queued behind a refused build
         bounds(cur ^ 1, cnt, chunks, dst);
         begin = end; end = newEnd;
         CrtTri* t = src; src = dst; dst = t;
         cur ^= 1;
     }
     const uint32_t numBuilt = end;
-    if (firstNode + numBuilt > g.nodeCap) return CRT_E_OUT_OF_RANGE;
+    if (firstNode + numBuilt > g.nodeCap) { (void)hipStreamSynchronize(st); return CRT_E_OUT_OF_RANGE; }
     // numbering in closed form (crt_bvh_build.h): leaf starts -> exclusive prefix counts S (flags in `rank`, S in `holes`..: total + 1 words) -> one pass
     {
         uint32_t* flags = rank; uint32_t* S = holes; uint32_t* sums = chunkL;
         const uint32_t nb = (uint32_t)(total / CRT_BVH_SCAN_ITEMS) + 1;
-        if (nb > maxChunks) return CRT_E_OUT_OF_RANGE;
+        if (nb > maxChunks) { (void)hipStreamSynchronize(st); return CRT_E_OUT_OF_RANGE; }
         HIPCHK(hipMemsetAsync(flags, 0, total * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(dScal, 0, 2 * sizeof(uint32_t), st));                     // [0] nodes used, [1] "a node number fell outside the node array"
         crt_bvh_leaf_flags<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, (uint32_t)firstTri, flags);
         crt_bvh_scan_sums<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums);
         crt_bvh_scan_blocks<<<1, CRT_BVH_SCAN_THREADS, 0, st>>>(sums, nb);
         crt_bvh_scan_apply<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums, S);
-        crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, numMeshes, S, (uint32_t)firstTri, (uint32_t)total, (uint32_t)firstNode, g.rawNodes, dRoots, dScal);
+        crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, numMeshes, S, (uint32_t)firstTri, (uint32_t)total, (uint32_t)firstNode, g.rawNodes, dRoots, dScal, dScal + 1);
         HIPCHK(hipGetLastError());
     }
-    uint32_t used = 0;
-    HIPCHK(hipMemcpyAsync(&used, dScal, sizeof used, hipMemcpyDeviceToHost, st));
+    uint32_t used = 0, scal[2] = { 0, 0 };
+    HIPCHK(hipMemcpyAsync(scal, dScal, sizeof scal, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(g.roots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(g.hRoots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     crt_relayout_tris<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.rawTris, firstTri, total, g.triHot, g.triCold);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
-    if (used != numBuilt) return CRT_E_OUT_OF_RANGE;                               // the closed form and the level loop disagree: never seen, would mean a damaged tree
+    used = scal[0];
+    if (scal[1] != 0 || used != numBuilt) return CRT_E_OUT_OF_RANGE;                               // the closed form and the level loop disagree: never seen, would mean a damaged tree
     if (firstNode + used > g.nodeCount) g.nodeCount = (uint32_t)(firstNode + used);
     if (firstMesh + (size_t)numMeshes > g.numRoots) g.numRoots = (uint32_t)(firstMesh + (size_t)numMeshes);
     if (nodesUsedOut) *nodesUsedOut = used;

@@ -333,18 +333,25 @@ void ResourceManager::PushMeshesToGPU() // ResourceManager.cpp:280-300
         const size_t addedTriangleSize = (numTriangles - lastTriangleCount) * sizeof(Tri);
         uint numNodesUsed = 0;
         int rc = crt_upload_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
-        if (rc == 0) rc = crt_build_bvh(lastTriangleCount, counts, newMeshes, lastBVHIndex, numberOfBVH, &numNodesUsed);
-        if (rc == 0) rc = crt_download_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
-        if (rc == 0) rc = crt_download_bvh_nodes(g_BVHNodes + lastBVHIndex, lastBVHIndex * sizeof(BVHNode), sizeof(BVHNode) * numNodesUsed);
-        if (rc == 0) rc = crt_download_bvh_roots(g_BVHIndices + numberOfBVH, numberOfBVH, (size_t)newMeshes);
-        note(rc, "crt_build_bvh");
-        if (rc != 0) return;
-        note(crt_upload_materials(g_Materials, 0, (size_t)numMaterials), "crt_upload_materials");
-        AdvanceBVHNodeCounter(numNodesUsed);
-        numberOfBVH = (uint)numMeshes;
-        lastBVHIndex += numNodesUsed;
-        lastTriangleCount = numTriangles;
-        return;
+        int built = rc;
+        if (rc == 0) built = crt_build_bvh(lastTriangleCount, counts, newMeshes, lastBVHIndex, numberOfBVH, &numNodesUsed);
+        if (rc == 0 && built != 0) {
+            // the device builder refused (a size beyond its scratch layout, or its consistency checks): the host arenas still hold the
+            // triangles as imported, so the host BuildBVH below takes over and its uploads replace whatever the device build left behind
+            std::fprintf(stderr, "[ResourceManager] crt_build_bvh failed (%d): building on the host\n", built);
+        } else {
+            if (rc == 0) rc = crt_download_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
+            if (rc == 0) rc = crt_download_bvh_nodes(g_BVHNodes + lastBVHIndex, lastBVHIndex * sizeof(BVHNode), sizeof(BVHNode) * numNodesUsed);
+            if (rc == 0) rc = crt_download_bvh_roots(g_BVHIndices + numberOfBVH, numberOfBVH, (size_t)newMeshes);
+            note(rc, "crt_build_bvh");
+            if (rc != 0) return;
+            note(crt_upload_materials(g_Materials, 0, (size_t)numMaterials), "crt_upload_materials");
+            AdvanceBVHNodeCounter(numNodesUsed);
+            numberOfBVH = (uint)numMeshes;
+            lastBVHIndex += numNodesUsed;
+            lastTriangleCount = numTriangles;
+            return;
+        }
     }
     const uint numNodesUsed = BuildBVH(g_Triangles + lastTriangleCount, meshInfos + numberOfBVH, numMeshes - (int)numberOfBVH,
                                        g_BVHNodes, g_BVHIndices + numberOfBVH);

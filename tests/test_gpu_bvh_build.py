@@ -184,3 +184,23 @@ def test_build_errors_are_codes(session):
     buf = np.zeros(64, np.uint8)
     assert hip.crt_download_triangles(buf.ctypes.data, 0, 81) == -2 and hip.crt_download_bvh_nodes(buf.ctypes.data, 0, 33) == -2
     assert hip.crt_download_bvh_roots(buf.ctypes.data, 127, 2) == -3 and hip.crt_download_triangles(None, 0, 80) == -2
+
+
+def test_a_refused_device_build_falls_back_to_the_host_builder(monkeypatch, capfd):
+    """ResourceManager::PushMeshesToGPU with SetDeviceBVHBuild(true): when crt_build_bvh refuses (forced here through the
+    CRT_DEBUG_HOOKS test hook; in production: a size beyond the builder's scratch layout or a failed consistency check), the
+    host BuildBVH (BVH.cpp:218-255 mirror) takes over -- same arenas, same frame as a session that never asked for the device build."""
+    sc = scenes.get("tiny")
+    with driver.Session(160, 96, device=0) as s:
+        s.load_scene(sc)
+        a = s.arenas()
+        want_nodes, want_tris = a["nodes"].tobytes(), a["tris"].tobytes()
+        s.render_raw(0); want = s.read_output().copy()
+    monkeypatch.setenv("CRT_DEBUG_HOOKS", "1"); monkeypatch.setenv("CRT_DEBUG_FAIL_BVH_BUILD", "1")
+    with driver.Session(160, 96, device=0) as s:
+        s.load_scene(sc, device_bvh_build=True)
+        a = s.arenas()
+        assert a["nodes"].tobytes() == want_nodes and a["tris"].tobytes() == want_tris
+        s.render_raw(0)
+        assert np.array_equal(s.read_output().view(np.uint32), want.view(np.uint32))
+    assert "building on the host" in capfd.readouterr().err
