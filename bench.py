@@ -85,7 +85,8 @@ def chain_ceiling():
             full, part = pick(64), pick(28)
             if full:
                 return {"full": full[0]["records_per_cycle_per_cu"], "lanes28": part[0]["records_per_cycle_per_cu"] if part else None,
-                        "clock_ghz": full[0]["clock_ghz"], "source": os.path.relpath(path, ROOT)}
+                        "clock_ghz": full[0]["clock_ghz"], "source": os.path.relpath(path, ROOT), "mix": full[0]["mix"],
+                        "hot": full[0].get("hot"), "warm": full[0].get("warm")}
         except Exception:
             continue
     return None
@@ -623,8 +624,8 @@ def main():
                      "frac_of_ceiling_at_28_lanes": None if ceil["lanes28"] is None else round(gather_rate / ceil["lanes28"], 4),
                      "ceiling_source": ceil["source"], "clock_ghz": round(clock_ghz, 4), "clock_source": clock_src, "cus": num_cus,
                      "note": "ceiling = tools/ubench/chain.hip: every lane of 8 waves/SIMD chasing its own chain of 64-B records (4 x dwordx4 + the inner step's "
-                             "arithmetic + LDS push per hop) at the trace kernel's measured hit mix (56 % of records L1-resident, 32 % from L2, 12 % from the "
-                             "Infinity Cache); the same rate from 2 to 8 waves/SIMD, i.e. a throughput limit of the CU's vector-memory path, not latency. The "
+                             "arithmetic + LDS push per hop) at the trace kernel's measured hit mix (" + str(ceil.get("mix")) + ": %.0f %% of records L1-resident, %.0f %% from L2, the rest from the "
+                             "Infinity Cache); the same rate from 2 to 8 waves/SIMD" % (100.0 * (ceil.get("hot") or 0.0), 100.0 * (ceil.get("warm") or 0.0)) + ", i.e. a throughput limit of the CU's vector-memory path, not latency. The "
                              "trace kernel runs with ~28 of 64 lanes working per vector instruction (ceiling_at_28_of_64_lanes) and its packets are partly "
                              "coherent (several lanes per record), which is how it can sit above that second figure"}
         out = {
@@ -776,6 +777,45 @@ def main():
                     if tr2:
                         out[key]["hbm"] = {"traffic": tr2, "traffic_source": src2, "achieved_gbs": round(tr2 / (out[key]["steady_state"]["ms_per_step"] * 1e-3) / 1e9, 1),
                                            "frac": round(tr2 / (out[key]["steady_state"]["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # the device BuildBVH (crt_build_bvh, SURVEY 8f rank 1: BVH.cpp:218-255 on the GPU, same bytes as the host builder) on the bench scene's
+            # triangles: best of 3 builds incl. the re-layout for rendering; bytes = what the level passes must move at least
+            try:
+                with driver.Session(64, 48, device=device_index) as sb:
+                    sb.load_scene(sc)
+                    ab = sb.arenas()
+                    hb = _lib.host()
+                    counts = []
+                    for m in range(hb.crth_num_meshes()):
+                        info = np.zeros(4, np.uint32); hb.crth_mesh_info(m, info.ctypes.data); counts.append(int(info[0]))
+                    cb = np.asarray(counts, np.uint32); trisb = np.ascontiguousarray(ab["tris"].copy())
+                    best_b, used_b = None, C.c_uint32(0)
+                    for _ in range(3):
+                        _lib.check(hip.crt_upload_triangles(trisb.ctypes.data, 0, trisb.nbytes), "crt_upload_triangles")
+                        t0 = time.perf_counter()
+                        _lib.check(hip.crt_build_bvh(0, cb.ctypes.data, len(cb), 0, 0, C.byref(used_b)), "crt_build_bvh")
+                        d = time.perf_counter() - t0
+                        best_b = d if best_b is None else min(best_b, d)
+                    nb = np.zeros(used_b.value, _lib.NODE_DTYPE); rb = np.zeros(len(cb), np.uint32)
+                    _lib.check(hip.crt_download_bvh_nodes(nb.ctypes.data, 0, nb.nbytes), "crt_download_bvh_nodes")
+                    _lib.check(hip.crt_download_bvh_roots(rb.ctypes.data, 0, len(rb)), "crt_download_bvh_roots")
+                    # every level reads the triangles of its open nodes three times (bounds, bins + sweep, partition) and writes them once:
+                    # 4 x 80 B x (sum over nodes of their triangle count) = 320 B x sum over leaves of count x (depth + 1)
+                    frontier, depth, tri_levels = rb.astype(np.int64), 1, 0
+                    while len(frontier):
+                        leaf = nb["triCount"][frontier] > 0
+                        tri_levels += int(nb["triCount"][frontier][leaf].sum()) * depth
+                        inner = frontier[~leaf]
+                        left = nb["leftFirst"][inner].astype(np.int64)
+                        frontier = np.concatenate([left, left + 1]); depth += 1
+                    moved = 320 * tri_levels
+                    out["bvh_build"] = {"ms": round(best_b * 1e3, 3), "triangles": int(len(trisb)), "nodes": int(used_b.value), "levels": depth - 1,
+                                        "bytes_moved": int(moved), "frac_of_hbm": round(moved / best_b / 1e9 / HBM_PEAK_GBS, 4),
+                                        "triangles_per_s": round(len(trisb) / best_b, 0),
+                                        "note": "crt_build_bvh incl. the re-layout for rendering, best of 3 (host wall clock around the call); bytes_moved = 320 B x the sum over all "
+                                                "nodes of their triangle count (three reads and one write of an 80-B Tri per open node and level): a lower bound; the build is "
+                                                "launch- and atomics-bound (~150 launches, one 16-B read-back per level), not bandwidth-bound"}
+            except Exception as e:  # pragma: no cover - an extra, never the reason for a missing line
+                out["bvh_build"] = {"error": str(e)}
             # BASELINE config 4 as written ("LDS stack + wavefront compaction on"): the wavefront form of Trace -- bounce 0, ballot compaction of
             # the continuing paths into a queue, bounce 1 as dense 64-ray packets (CRT_KERNEL=wavefront, read by crt_init) -- on the bench frame.
             # Bit-identical to the default kernel and to the oracle at this size (tests/test_gpu_variants.py); slower, which is why it is opt-in.

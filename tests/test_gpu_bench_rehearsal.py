@@ -87,6 +87,7 @@ def test_single_gpu_line_carries_the_contract_and_the_round_3_objects():
     assert "stagger" in d["config"] and "3840x2160" in d["config"]["n_gt_1_lines"]
     for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "scale_base_n1", "wavefront_compaction"):
         assert d[key]["value"] > 0 and d[key]["rays_per_frame"] > 0, key
+    assert 0 < d["bvh_build"]["ms"] < 100 and d["bvh_build"]["nodes"] > d["bvh_build"]["triangles"] and 0 < d["bvh_build"]["frac_of_hbm"] < 1
     assert d["wavefront_compaction"]["synchronous_frames"] > 0 and d["wavefront_compaction"]["rays_per_frame"] == d["config"]["rays_per_frame"]
     assert d["with_shadow_rays"]["shadow_rays_per_frame"] > 0 and d["dense_view"]["primary_hit_fraction"] > 0.9
     assert d["steady_state"]["value"] > 0 and d["synchronous_frames"]["value"] > 0

@@ -356,7 +356,14 @@ int main(int argc, char** argv)
     hipMalloc(&dOut, (size_t)maxWaves * 64 * 4); hipMalloc(&dStamps, (size_t)maxWaves * 3 * 8);
     uint32_t* dMismatch; hipMalloc(&dMismatch, 8);
     struct Mix { const char* name; float hot, warm; };
-    const Mix mixes[] = { { "kernel mix (multi-1M: 89 % L1 line hits, 72 % L2 hits)", 0.56f, 0.317f },
+    // the trace kernel's hit mix: CHAIN_MIX="<L1 line hit rate>,<L2 hit rate>" (fractions, from the newest profiles/r*_summary.json: l1_hit_rate,
+    // l2_hit_rate) replaces the round-2 figures: a record is 4 line accesses of which the last 3 always hit, so 4 x (1 - l1) of the RECORDS miss L1
+    float l1 = 0.89f, l2 = 0.72f;
+    if (const char* e = getenv("CHAIN_MIX")) { float a = 0, b = 0; if (sscanf(e, "%f,%f", &a, &b) == 2 && a > 0.75f && a <= 1.0f && b >= 0.0f && b <= 1.0f) { l1 = a; l2 = b; } }
+    static char mixName[128];
+    snprintf(mixName, sizeof mixName, "kernel mix (multi-1M: %.1f %% L1 line hits, %.1f %% L2 hits)", l1 * 100.0f, l2 * 100.0f);
+    const float missRec = 4.0f * (1.0f - l1);
+    const Mix mixes[] = { { mixName, 1.0f - missRec, missRec * l2 },
                           { "all records L1-resident", 1.0f, 0.0f },
                           { "all records from L2", 0.0f, 1.0f },
                           { "all records from the Infinity Cache", 0.0f, 0.0f } };
