@@ -17,7 +17,7 @@ HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
 
 EXAMPLE = examples/crt_headless
 
-UBENCH = tools/ubench/gather tools/ubench/chain
+UBENCH = tools/ubench/gather tools/ubench/chain tools/ubench/cumask
 
 all: $(HIP_SO) $(HOST_SO) $(EXAMPLE) $(UBENCH) oracle
 
@@ -27,6 +27,10 @@ tools/ubench/gather: tools/ubench/gather.hip
 # dependent-chain 64-B gather microbenchmark: the ceiling bench.py's roofline.chain is taken against (profiles/r03_ubench_chain.*)
 tools/ubench/chain: tools/ubench/chain.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -Wno-unused-value -Wno-uninitialized -Wno-sometimes-uninitialized -o $@ $<
+
+# CU-mask probe: hipExtStreamCreateWithCUMask on this part, and which CU each mask bit names (round 4's reserved-CU experiment)
+tools/ubench/cumask: tools/ubench/cumask.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 
 # the reference's EngineMain loop over the mirrored C++ API
 $(EXAMPLE): examples/headless_main.cpp $(HOST_SO)
