@@ -9,7 +9,7 @@
 //   crt_order_kernel        feedback launch lists: per-XCD counting sort of the tiles by last frame's cost
 // Device-side traversal/shading code lives in crt_device.h. (Two further kernel structures of round 1 -- resident waves
 // pulling tiles from per-XCD queues, and 768-thread workgroups with the hot BVH tiles staged in LDS -- were measured
-// at 1.67 and 2.25 Gray/s against 4.55 for this one and retired in round 2; DESIGN.md keeps the numbers.)
+// at 1.67 and 2.25 Gray/s against 4.55 for this one and retired in round 2; docs/DESIGN_HISTORY.md 4f keeps the numbers.)
 #pragma once
 #include "crt_device.h"
 

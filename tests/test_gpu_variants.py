@@ -13,7 +13,7 @@ FLAG_COUNT = 8
 def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     """The opt-in kernel structure (CRT_KERNEL=wavefront: one launch per bounce with ballot compaction in between) renders
     the same bits and counts the same work as the default megakernel. (Round 1's `persistent` and `lds` structures were
-    retired in round 2; DESIGN.md keeps their measurements.)"""
+    retired in round 2; docs/DESIGN_HISTORY.md 4f keeps their measurements.)"""
     sc = scenes.get("tiny")
     POST, ASYNC, UNORM8, FXAA = 1, 4, 64, 512
     stages = (POST, UNORM8, POST | UNORM8, POST | UNORM8 | ASYNC, FXAA | UNORM8, FXAA | POST | UNORM8)
