@@ -361,6 +361,10 @@ void rebuild_instance_master()
     }
     g.bounceOriginReach = (float)reach;
     double minLimit = 1e30;
+    // test hook (CRT_DEBUG_HOOKS=1 only): CRT_DEBUG_CULL_RANGE_SCALE=k multiplies every O_i -- tools/fuzz_cull.py uses it to measure how far
+    // beyond the proven range the cull stays exact in practice (the derivation is a worst-case bound)
+    double rangeScale = 1.0;
+    { const char* h = getenv("CRT_DEBUG_HOOKS"); const char* k = getenv("CRT_DEBUG_CULL_RANGE_SCALE"); if (h && atoi(h) != 0 && k && atof(k) > 0.0) rangeScale = atof(k); }
     const double U = 5.9604644775390625e-8, G3 = 3.0 * U / (1.0 - 3.0 * U), G4 = 4.0 * U / (1.0 - 4.0 * U), K = 2.8e-6;
     for (uint32_t i = 0; i < CRT_MAX_INSTANCES; ++i) {
         bounds[i] = make_float4(0.f, 0.f, 0.f, -1.0f);
@@ -403,7 +407,8 @@ void rebuild_instance_master()
         for (int c = 0; c < 3; ++c) t2 += inv[12 + c] * inv[12 + c];
         const double kappa = sqrt(m3) * sqrt(f3), tau = sqrt(t2) * sqrt(f3), c1 = (1.0 + sqrt(3.0)) * G3 * kappa;
         const double inside = 1.02 * (1.0 - c1 * c1 / K);
-        const double limit = inside > 0.0 ? ((double)rf * (sqrt(inside) - 1.0 - c1) - G4 * tau) / (G4 * kappa) : -1.0;
+        double limit = inside > 0.0 ? ((double)rf * (sqrt(inside) - 1.0 - c1) - G4 * tau) / (G4 * kappa) : -1.0;
+        limit *= rangeScale;                  // 1 unless the test hook below stretches the range to find where the cull really starts to err
         if (!(limit >= reach)) continue;      // (also NaN) never culled: bounce rays alone would leave the proven range
         g.hCullOriginLimit[i] = (float)fmin(limit * (1.0 - 1e-6), 3e38);
         if (limit < minLimit) minLimit = limit;
