@@ -215,3 +215,13 @@ def test_frames_from_far_cameras(sess):
             assert rmse(gpu, ref) < 1e-4 and int((dlt > 1e-5).sum()) <= int(1e-5 * dlt.size) + 1, (name, norm, k)
             if np.linalg.norm(pos.astype(np.float64)) > scene_lim:
                 assert _culled(s) == 0
+
+
+def test_fuzz_tool_runs_clean_on_a_few_seeds():
+    """tools/fuzz_cull.py (random instance matrices, origins inside / at / beyond the proven range; profiles/r04_fuzz_cull.txt) stays runnable."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_cull.py"), "5000", "6"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "all hit records and counters equal the oracle's" in p.stdout, p.stdout[-2000:]
