@@ -212,6 +212,15 @@ struct CrtBigScratch {
     uint32_t bbmin[3 * CRT_BVH_BINS * 3], bbmax[3 * CRT_BVH_BINS * 3];
 };
 struct CrtBuildCtl { unsigned long long packed; uint32_t nextChunks; uint32_t degenerate; };   // read back by the host after every level
+// The read-back: the last launch of a level copies its control record into pinned host memory and then raises `seq`; the host, which needs
+// the list sizes to shape the next level's launches, spins on `seq` instead of paying a copy + stream synchronisation per level.
+struct CrtBuildCtlHost { CrtBuildCtl ctl; volatile uint32_t seq; uint32_t pad[3]; };
+__global__ void crt_bvh_publish(const CrtBuildCtl* __restrict__ ctl, CrtBuildCtlHost* __restrict__ host, uint32_t seq)
+{
+    host->ctl.packed = ctl->packed; host->ctl.nextChunks = ctl->nextChunks; host->ctl.degenerate = ctl->degenerate;
+    __threadfence_system();
+    host->seq = seq;
+}
 __host__ __device__ __forceinline__ uint32_t bvh_chunks(uint32_t n) { return (n + CRT_BVH_CHUNK - 1) / CRT_BVH_CHUNK; }
 
 // sum over the workgroup; every thread gets the total. s_red: one word per wave
@@ -742,7 +751,9 @@ template <int N>
 __device__ __forceinline__ void bvh_tiny_body(CrtBuildNode* __restrict__ nodes, CrtBuildNode& node, const bool live, const uint32_t first, const uint32_t n,
                                               CrtTri* __restrict__ src, CrtTri* __restrict__ dst, uint32_t levelEnd, unsigned long long* __restrict__ packed, const CrtBuildLists& next)
 {
-    float tmn[N][3], tmx[N][3], cen[N][3];
+    // (the centroids are re-read where they are used -- per axis for the bins, once more for the partition: kept in registers next to the
+    // 48 box floats they pushed the 8-triangle instantiation to 103 VGPRs + 160 B of scratch)
+    float tmn[N][3], tmx[N][3];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if ((uint32_t)i < n) {
@@ -752,26 +763,29 @@ __device__ __forceinline__ void bvh_tiny_body(CrtBuildNode* __restrict__ nodes, 
                 float lo = 1e30f, hi = -1e30f;
 #pragma unroll
                 for (int v = 0; v < 3; ++v) { const float x = t[4 * v + c]; lo = lo < x ? lo : x; hi = hi > x ? hi : x; }
-                tmn[i][c] = lo; tmx[i][c] = hi; cen[i][c] = t[3 + 4 * c];
+                tmn[i][c] = lo; tmx[i][c] = hi;
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { tmn[i][c] = 1e30f; tmx[i][c] = -1e30f; cen[i][c] = 0.0f; }
+            for (int c = 0; c < 3; ++c) { tmn[i][c] = 1e30f; tmx[i][c] = -1e30f; }
         }
     }
     float bestCost = 1e30f, splitPos = 0.0f; int bestAxis = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float boundsMin = 1e30f, boundsMax = -1e30f;
+        float cen[N];                                          // this axis' centroids
+#pragma unroll
+        for (int i = 0; i < N; ++i) cen[i] = (uint32_t)i < n ? bvh_centroid(src, (size_t)first + i, a) : 0.0f;
 #pragma unroll
         for (int i = 0; i < N; ++i)
-            if ((uint32_t)i < n) { const float v = cen[i][a]; boundsMin = boundsMin < v ? boundsMin : v; boundsMax = boundsMax > v ? boundsMax : v; }
+            if ((uint32_t)i < n) { const float v = cen[i]; boundsMin = boundsMin < v ? boundsMin : v; boundsMax = boundsMax > v ? boundsMax : v; }
         if (boundsMax == boundsMin) continue;
         const float scale = (float)CRT_BVH_BINS / (boundsMax - boundsMin);
         int bin[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            int b = f2i((cen[i][a] - boundsMin) * scale);
+            int b = f2i((cen[i] - boundsMin) * scale);
             b = (CRT_BVH_BINS - 1) < b ? (CRT_BVH_BINS - 1) : b;
             if (b < 0) b = 0;
             bin[i] = (uint32_t)i < n ? b : CRT_BVH_BINS;          // absent triangles are on neither side
@@ -807,8 +821,7 @@ __device__ __forceinline__ void bvh_tiny_body(CrtBuildNode* __restrict__ nodes, 
     uint32_t left = 0;                                         // bit i: centroid of triangle i is left of the plane
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const float c = bestAxis == 0 ? cen[i][0] : (bestAxis == 1 ? cen[i][1] : cen[i][2]);
-        if ((uint32_t)i < n && c < splitPos) left |= 1u << i;
+        if ((uint32_t)i < n && bvh_centroid(src, (size_t)first + i, bestAxis) < splitPos) left |= 1u << i;
     }
     static_assert(N <= 16 && N <= CRT_BVH_TINY, "the permutation is packed four bits per entry into 64 bits");
     unsigned long long perm = 0xFEDCBA9876543210ull;

@@ -114,6 +114,7 @@ struct State {
     int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
+    CrtBuildCtlHost* buildCtlHost = nullptr; uint32_t buildSeq = 0;   // pinned: the per-level control record the builder publishes (crt_bvh_publish)
     CrtTri* buildTris = nullptr;                               // crt_build_bvh: second triangle pool (same indexing as rawTris)
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
     uint32_t nodeCount = 0, numRoots = 0; size_t texelBytesHigh = 0; size_t trisHigh = 0;
@@ -667,6 +668,7 @@ static void release_all()
     }
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.statStart) (void)hipEventDestroy(g.statStart);
+    if (g.buildCtlHost) (void)hipHostFree(g.buildCtlHost);
     for (FrameSlot& fs : g.slot) {
         for (EventSet& es : fs.es) for (int i = 0; i < 4; ++i) if (es.ev[i]) (void)hipEventDestroy(es.ev[i]);
         if (fs.stream) (void)hipStreamDestroy(fs.stream);
@@ -824,6 +826,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     // second triangle pool (allocated on first use, indexed like rawTris) and scratch:
     // build nodes | rank, holes, backL | 2 x 3 id lists | 2 x BIG-node scratch | 2 x chunk->node + 3 per-chunk counts | mesh counts, roots | scalars
     if (!g.buildTris) HIPCHK(hipMalloc(&g.buildTris, g.triCap * sizeof(CrtTri)));
+    if (!g.buildCtlHost) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g.buildCtlHost), sizeof(CrtBuildCtlHost), hipHostMallocDefault)); g.buildCtlHost->seq = 0; g.buildSeq = 0; }
     const size_t maxNodes = 2 * total + (size_t)numMeshes;
     const size_t offNodes = 0;
     const size_t offRank = (offNodes + maxNodes * sizeof(CrtBuildNode) + 255) & ~(size_t)255;
@@ -911,8 +914,21 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         if (cnt[1]) crt_bvh_mid<<<(cnt[1] + W - 1) / W, 64 * W, 0, st>>>(bn, L.list[1], cnt[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, &dCtl->packed, N);
         if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, &dCtl->packed, N);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&ctl, dCtl, sizeof ctl, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        {   // the level's list sizes: published into pinned memory behind the level's kernels; spin on the sequence number (a copy + stream
+            // synchronisation per level cost ~40 us x 23 levels of a 1 M-triangle build), fall back to the stream if it does not arrive
+            const uint32_t seq = ++g.buildSeq;
+            crt_bvh_publish<<<1, 1, 0, st>>>(dCtl, g.buildCtlHost, seq);
+            HIPCHK(hipGetLastError());
+            bool arrived = false;
+            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+                if (g.buildCtlHost->seq == seq) { arrived = true; break; }
+                if ((spin & 0x3FFu) == 0x3FFu && hipStreamQuery(st) != hipErrorNotReady) break;      // finished (or failed) without our flag: let the sync below sort it out
+                __builtin_ia32_pause();
+            }
+            if (!arrived) { HIPCHK(hipStreamSynchronize(st)); if (g.buildCtlHost->seq != seq) return CRT_E_UNSUPPORTED; }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            ctl = g.buildCtlHost->ctl;
+        }
         if (ctl.degenerate) {                                                      // BVH.cpp:194 hit a BIG node: its permuted triangles go to both buffers
             crt_bvh_big_degenerate<<<chunks, T, 0, st>>>(bn, L.list[0], bigs[cur], chunkNode[cur], src, dst);
             crt_bvh_big_degenerate_mark<<<(cnt[0] + 255) / 256, 256, 0, st>>>(bn, L.list[0], bigs[cur], cnt[0]);
