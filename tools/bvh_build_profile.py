@@ -25,7 +25,7 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_bvh_build.md"), "w") as f:
     f.write(f"# `crt_build_bvh` on MI355X — rocprofv3 `--kernel-trace` of `python3 tools/bvh_build_time.py multi-1M` (last of 3 builds, round {tag[1:]})\n\n")
     if line:
         f.write(line[-1].strip() + " (timings under the profiler)\n\n")
-    f.write(f"{len(seg)} launches, {sum(v[1] for v in acc.values()) / 1e6:.2f} ms of kernel time inside a {(seg[-1][2] - seg[0][1]) / 1e6:.2f} ms span (one 16-byte read-back per level).\n\n")
+    f.write(f"{len(seg)} launches, {sum(v[1] for v in acc.values()) / 1e6:.2f} ms of kernel time inside a {(seg[-1][2] - seg[0][1]) / 1e6:.2f} ms span (one control record published to pinned host memory per level; r3: a 16-byte copy + stream synchronisation per level).\n\n")
     f.write("| kernel | launches | ms | longest launch us |\n|---|---|---|---|\n")
     for k, v in sorted(acc.items(), key=lambda x: -x[1][1]):
         f.write(f"| `{k}` | {v[0]} | {v[1] / 1e6:.3f} | {v[2] / 1e3:.0f} |\n")
