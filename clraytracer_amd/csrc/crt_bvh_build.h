@@ -69,7 +69,9 @@ __global__ void crt_bvh_centroids(CrtTri* __restrict__ tris, size_t first, size_
 // CRT_BVH_CHUNK triangles, one workgroup per chunk (crt_bvh_big_*); MID nodes get one wave each (crt_bvh_bounds_wave, crt_bvh_mid);
 // TINY nodes (<= CRT_BVH_TINY triangles -- the bulk of the deep levels: the builder splits down to one or two triangles per leaf) get
 // one THREAD each that replays upstream's sequential code literally (crt_bvh_tiny).
-#define CRT_BVH_SMALL 1024            // (2048 measured 2-10 % slower: the first wave-per-node levels are a few dozen long single-wave loops)
+#ifndef CRT_BVH_SMALL
+#define CRT_BVH_SMALL 512             // (1024: 3-10 % slower, 2048: 5-20 %: the first wave-per-node levels are a few dozen long single-wave loops; 256: the same as 512)
+#endif
 #ifndef CRT_BVH_TINY
 #define CRT_BVH_TINY 8
 #endif
@@ -77,7 +79,7 @@ enum { CRT_BVH_CLASS_BIG = 0, CRT_BVH_CLASS_MID = 1, CRT_BVH_CLASS_TINY = 2 };
 __host__ __device__ __forceinline__ int bvh_class(uint32_t count) { return count > CRT_BVH_SMALL ? CRT_BVH_CLASS_BIG : (count > CRT_BVH_TINY ? CRT_BVH_CLASS_MID : CRT_BVH_CLASS_TINY); }
 // Children are appended to the node array and to next level's lists with ONE 64-bit atomic per splitting node (per wave
 // in crt_bvh_tiny): the counter packs next level's three list sizes -- TINY in bits 0..23, MID in 24..43 (a MID node has
-// more than 8 triangles: < 2^20 of them per level), BIG in 44..55 (more than CRT_BVH_SMALL = 1024 triangles: < 2^12 of them in the 2.4 M-triangle pool) -- and because every
+// more than 8 triangles: < 2^20 of them per level), BIG in 44..63 (more than CRT_BVH_SMALL = 512 triangles: < 2^13 of them in the 2.4 M-triangle pool) -- and because every
 // child takes exactly one list slot, the number of children created so far is the sum of the three fields, which
 // numbers the new nodes. (Three separate same-address atomics per node cost 20 of the 34 ms of a 1 M-triangle build.)
 #define CRT_BVH_PACK_TINY(x) ((unsigned long long)(x))
@@ -85,7 +87,7 @@ __host__ __device__ __forceinline__ int bvh_class(uint32_t count) { return count
 #define CRT_BVH_PACK_BIG(x) ((unsigned long long)(x) << 44)
 __host__ __device__ __forceinline__ uint32_t bvh_unpack(unsigned long long p, int cls)
 {
-    return cls == CRT_BVH_CLASS_TINY ? (uint32_t)(p & 0xFFFFFFull) : (cls == CRT_BVH_CLASS_MID ? (uint32_t)((p >> 24) & 0xFFFFFull) : (uint32_t)((p >> 44) & 0xFFFull));
+    return cls == CRT_BVH_CLASS_TINY ? (uint32_t)(p & 0xFFFFFFull) : (cls == CRT_BVH_CLASS_MID ? (uint32_t)((p >> 24) & 0xFFFFFull) : (uint32_t)((p >> 44) & 0xFFFFFull));
 }
 __host__ __device__ __forceinline__ unsigned long long bvh_pack_one(int cls)
 {

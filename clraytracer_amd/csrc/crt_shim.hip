@@ -816,7 +816,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     if (firstTri + total > g.trisHigh) return CRT_E_BAD_ARGUMENT;                  // triangles must have been uploaded
     if (firstTri + total > 0x00FFFFFFu) return CRT_E_OUT_OF_RANGE;                 // leaf references carry 24-bit triangle indices
     if (firstNode + 2 * total > g.nodeCap) return CRT_E_OUT_OF_RANGE;              // a mesh of n triangles needs at most 2n-1 nodes
-    if (total / CRT_BVH_SMALL >= 4096 || total / CRT_BVH_TINY >= (1u << 20)) return CRT_E_OUT_OF_RANGE;   // field widths of the packed per-level counter (crt_bvh_build.h)
+    if (total / CRT_BVH_SMALL >= (1u << 20) || total / CRT_BVH_TINY >= (1u << 20)) return CRT_E_OUT_OF_RANGE;   // field widths of the packed per-level counter (crt_bvh_build.h)
     {   // test hook (CRT_DEBUG_HOOKS=1 only): refuse, so that the caller's fall-back to the host BuildBVH can be exercised
         const char* h = getenv("CRT_DEBUG_HOOKS"); const char* f = getenv("CRT_DEBUG_FAIL_BVH_BUILD");
         if (h && atoi(h) != 0 && f && atoi(f) != 0) return CRT_E_OUT_OF_RANGE;
