@@ -29,9 +29,41 @@ static inline f3 f3_cross(f3 a, f3 b)
 {
     return f3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+/* ---- Implementation-defined builtins -------------------------------------------------------------------------------------
+ * Default: the pinned semantics of crt_oracle.h (what the HIP path is held to, bit for bit).
+ * ORC_ALT_BUILTINS (oracle/Makefile target `sensitivity`, used ONLY by tests/test_oracle_sensitivity.py): the OTHER choices a
+ * conforming OpenCL implementation may make for the same source -- native_recip / the reciprocal square root inside normalize off
+ * by one ulp either way (a hardware estimate), single-precision atan2 / acos / sin / cos instead of correctly rounded ones -- so that
+ * the distance between two legal readings of the reference can be MEASURED (what "parity unpinned" means in
+ * pixels). Together with -ffp-contract=fast -mfma (OpenCL C's default FP_CONTRACT ON lets the compiler fuse a*b+c) that is the
+ * "alt" library. Never linked into the product, never used as the checker of the HIP path. */
+#ifdef ORC_ALT_BUILTINS
+static inline float orc_wobble(float r)
+{   /* +-1 ulp, the direction taken from the value's own bits: deterministic, unbiased */
+    uint32_t u; memcpy(&u, &r, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u || (u & 0x7FFFFFFFu) == 0u) return r;      /* inf, NaN, zero: as they are */
+    uint32_t h = u * 2654435761u; h ^= h >> 15;
+    if ((h & 3u) == 0u) return r;                                                      /* a quarter of the values come out exact */
+    u = (h & 4u) ? u + 1u : u - 1u;
+    float q; memcpy(&q, &u, 4); return q;
+}
+#define ORC_RECIP(x) orc_wobble(1.0f / (x))
+#define ORC_RSQRT(x) orc_wobble((float)(1.0 / sqrt((double)(x))))
+#define ORC_ATAN2PI(y, x) (atan2f((y), (x)) / 3.14159265f)
+#define ORC_ACOSPI(x) (acosf(x) / 3.14159265f)
+#define ORC_SIN(x) sinf(x)
+#define ORC_COS(x) cosf(x)
+#else
+#define ORC_RECIP(x) (1.0f / (x))
+#define ORC_RSQRT(x) (1.0f / sqrtf(x))
+#define ORC_ATAN2PI(y, x) ((float)(atan2((double)(y), (double)(x)) / ORC_PI))
+#define ORC_ACOSPI(x) ((float)(acos((double)(x)) / ORC_PI))
+#define ORC_SIN(x) ((float)sin((double)(x)))
+#define ORC_COS(x) ((float)cos((double)(x)))
+#endif
 static inline f3 f3_normalize(f3 v)
 {
-    float inv = 1.0f / sqrtf(f3_dot(v, v));
+    float inv = ORC_RSQRT(f3_dot(v, v));
     return f3_scale(v, inv);
 }
 /* MathAndSTL.cl:117-119  v - n * dot(n, v) * 2.0f */
@@ -111,7 +143,7 @@ static inline int intersect_triangle(Ray ray, const CrtTri* tri, Triout* o, int 
     const f3 edge2 = f3_sub(tz, tx);
     const f3 h = f3_cross(ray.direction, edge2);
     const float a = f3_dot(edge1, h);
-    const float f = 1.0f / a;
+    const float f = ORC_RECIP(a);
     const f3 s = f3_sub(ray.origin, tx);
     const float u = f * f3_dot(s, h);
     const f3 q = f3_cross(s, edge1);
@@ -171,7 +203,7 @@ static int intersect_bvh_ex(Ray ray, const CrtBVHNode* nodes, uint32_t rootNode,
     memset(nodesToVisit, 0, sizeof nodesToVisit);
     nodesToVisit[0] = (int32_t)rootNode;
     int currentNodeIndex = 1;
-    f3 invDir = f3_make(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    f3 invDir = f3_make(ORC_RECIP(ray.direction.x), ORC_RECIP(ray.direction.y), ORC_RECIP(ray.direction.z));
     int intersection = 0, protection = 0;
     st->traversals++;
 
@@ -258,8 +290,8 @@ static inline int64_t clamp_texel(int64_t idx, int64_t n)
 
 int orc_sample_skybox(const float d[3], const CrtTexture* tex)
 {
-    float at = (float)(atan2((double)d[0], (double)(-d[2])) / ORC_PI);
-    float ac = (float)(acos((double)d[1]) / ORC_PI);
+    float at = ORC_ATAN2PI(d[0], -d[2]);
+    float ac = ORC_ACOSPI(d[1]);
     int32_t theta = f2i((at * 0.5f) * (float)tex->width);
     int32_t phi = f2i(ac * (float)tex->height);
     /* mad24(phi, width, theta + 2) */
@@ -498,8 +530,8 @@ void orc_trace_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays
                   int row0, int row1, float* out, OrcStats* stats, int nthreads, int extensions)
 {
     (void)height;
-    const float lightY = (float)sin((double)args->sunAngle);
-    const float lightZ = (float)cos((double)args->sunAngle);
+    const float lightY = ORC_SIN(args->sunAngle);
+    const float lightZ = ORC_COS(args->sunAngle);
     if (nthreads < 1) nthreads = 1;
     OrcStats total; memset(&total, 0, sizeof total);
 #pragma omp parallel num_threads(nthreads)
@@ -529,8 +561,8 @@ void orc_trace_costs(const OrcScene* s, const CrtTraceArgs* args, const float* r
 void orc_trace_costs_ex(const OrcScene* s, const CrtTraceArgs* args, const float* rays, int width, int height,
                         uint32_t* innerOut, uint32_t* triOut, int nthreads, int extensions)
 {
-    const float lightY = (float)sin((double)args->sunAngle);
-    const float lightZ = (float)cos((double)args->sunAngle);
+    const float lightY = ORC_SIN(args->sunAngle);
+    const float lightZ = ORC_COS(args->sunAngle);
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
     for (int j = 0; j < height; ++j) {

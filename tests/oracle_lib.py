@@ -28,14 +28,31 @@ class CrtTraceArgs(C.Structure):
 
 
 _lib = None
+_libs = {}
 
 
-def lib():
+def lib(path=None):
+    """The oracle library (default: the pinned one). `path`: another build of the same source -- only tests/test_oracle_sensitivity.py
+    passes one (oracle/Makefile `sensitivity`)."""
     global _lib
+    if path is not None:
+        if path not in _libs:
+            saved, _lib = _lib, None
+            try:
+                _libs[path] = _load(path)
+            finally:
+                _lib = saved
+        return _libs[path]
     if _lib is None:
-        if not os.path.exists(ORACLE_SO):
-            raise ImportError(f"{ORACLE_SO} missing: run `make -C oracle`")
-        L = C.CDLL(ORACLE_SO)
+        _lib = _load(ORACLE_SO)
+    return _lib
+
+
+def _load(so):
+    if True:
+        if not os.path.exists(so):
+            raise ImportError(f"{so} missing: run `make -C oracle`")
+        L = C.CDLL(so)
         fp = C.POINTER(C.c_float)
         L.orc_float_to_half.restype = C.c_uint16; L.orc_float_to_half.argtypes = [C.c_float]
         L.orc_half_to_float.restype = C.c_float; L.orc_half_to_float.argtypes = [C.c_uint16]
@@ -67,8 +84,7 @@ def lib():
         L.orc_closest_hits.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(OrcStats), C.c_int]
         L.orc_cpu_raycast.restype = None
         L.orc_cpu_raycast.argtypes = [C.POINTER(OrcScene), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-        _lib = L
-    return _lib
+    return L
 
 
 def f32(a):
@@ -88,7 +104,8 @@ def fxaa(img, row0=0, row1=None):
 class Oracle:
     """Holds numpy copies of a scene's arenas and runs the oracle kernels on them."""
 
-    def __init__(self, arenas, nthreads=None):
+    def __init__(self, arenas, nthreads=None, so=None):
+        self.so = so          # None: the pinned oracle; a path: another build of the same source (sensitivity study only)
         self.a = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in arenas.items()}
         self.nthreads = nthreads or min(16, os.cpu_count() or 1)
         a = self.a
@@ -102,7 +119,7 @@ class Oracle:
     def raygen(self, width, height, inv_view, inv_proj):
         rays = np.empty((height, width, 3), np.float32)
         p1, k1 = f32(inv_view); p2, k2 = f32(inv_proj)
-        lib().orc_raygen(rays.ctypes.data, width, height, p1, p2)
+        lib(self.so).orc_raygen(rays.ctypes.data, width, height, p1, p2)
         return rays
 
     def trace(self, rays, cam_pos, sun_angle, row0=0, row1=None, shadows=False, refraction=False):
@@ -114,7 +131,7 @@ class Oracle:
         args.time = 0.0; args.numMeshes = self.s.numInstances; args.sunAngle = float(sun_angle)
         st = OrcStats()
         rays = np.ascontiguousarray(rays, np.float32)
-        lib().orc_trace_ex(C.byref(self.s), C.byref(args), rays.ctypes.data, w, h, row0, row1, out.ctypes.data, C.byref(st), self.nthreads,
+        lib(self.so).orc_trace_ex(C.byref(self.s), C.byref(args), rays.ctypes.data, w, h, row0, row1, out.ctypes.data, C.byref(st), self.nthreads,
                            (1 if shadows else 0) | (2 if refraction else 0))
         return out, st.as_dict()
 
@@ -145,7 +162,7 @@ class Oracle:
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3); d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
         out = np.zeros(len(o), RAYHIT_DTYPE)
         st = OrcStats()
-        lib().orc_closest_hits(C.byref(self.s), o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data, C.byref(st), self.nthreads)
+        lib(self.so).orc_closest_hits(C.byref(self.s), o.ctypes.data, d.ctypes.data, len(o), out.ctypes.data, C.byref(st), self.nthreads)
         return out, st.as_dict()
 
     def cpu_raycast(self, origins, dirs):
