@@ -25,8 +25,9 @@ launch outside the timed region (and checked against the oracle in tests/).
 
 The JSON line also carries
   roofline     : the contract's HBM roofline of the dominant kernel (crt_trace_kernel): `bound` "hbm", `achieved` = bytes that really
-                 leave L2 per launch (`traffic`: FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 --pmc passes of this command,
-                 `traffic_source`; null when no profile of this workload is committed) / the device time per launch measured
+                 leave L2 per launch (`traffic`: FETCH_SIZE + WRITE_SIZE of rocprofv3 --pmc passes of this command -- measured by two short child runs
+                 of this very run (`traffic_source` "live: ..."; --no-live-pmc or any failure falls back to the committed passes,
+                 `traffic_committed_profile`); null when neither exists) / the device time per launch measured
                  live with HIP events on the launch streams, `peak` = 8 TB/s, `frac` = achieved / peak (never printed above 1).
                  SURVEY.md 8d's layout-independent ALGORITHMIC bytes are `algorithmic_*`: they exceed what reaches HBM 30x over
                  (L1/L2/Infinity Cache, the instance cull), so `algorithmic_over_hbm_peak` (> 1) is a work measure, not a
@@ -247,6 +248,43 @@ def secondary_ceilings(kernel, workload_scene, width, height, dev_s):
     return out
 
 
+def live_pmc_traffic(scene, width, height, timeout_s=150):
+    """HBM-side bytes per launch measured NOW: two child runs of this script under `rocprofv3 --kernel-trace --pmc <one counter>` (FETCH_SIZE,
+    then WRITE_SIZE: separate passes, nothing else traced, the program itself after `--`), mean per launch of the timed region's kernel.
+    Returns (bytes, description) or (None, reason). Any failure -- no rocprofv3, a pass that times out, no matching rows -- falls back to the
+    committed profile; the parent process only waits (its own frames are done)."""
+    import csv, glob, shutil, subprocess, tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    kern = "crt_trace_kernel<false, false, false, false, false>"
+    total, launches = 0.0, []
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="crt_pmc_", dir="/tmp")
+        cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--scene", scene, "--width", str(width), "--height", str(height)]
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("CRT_KERNEL", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+                for r in csv.DictReader(open(f)):
+                    if kern in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if p.returncode != 0 or not vals:
+                return None, f"{counter} pass: rc {p.returncode}, {len(vals)} launches"
+            total += sum(vals) / len(vals)
+            launches.append(len(vals))
+        except Exception as e:  # noqa: BLE001 - a measurement aid must never take the bench line down
+            return None, f"{counter} pass: {type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return int(total * 1024), (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 5` spawned by this run "
+                               f"(mean over {launches[0]} / {launches[1]} launches of {kern}; KiB counters x 1024)")
+
+
 def pmc_traffic(kernel, workload_scene, width, height):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_summary.json:
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same command, newest round first). FETCH_SIZE is exact
@@ -286,6 +324,7 @@ def main():
     ap.add_argument("--diag-mix3", action="store_true", help="profiling aid: every step is ONE dispatch tracing the frame three times with interleaved tile lists "
                                                              "(CRT_RENDER_DIAG_MIX3: the wave mix of three frames in flight, visible to a PMC pass); synchronous; rates are per 3 frames")
     ap.add_argument("--prewarm-ms", type=float, default=100.0, help="untimed rendering before the warm-up steps, so that the timed steps do not measure the clock ramp of an idle GPU")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed profile instead of measuring it now with two short rocprofv3 --pmc child runs")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     if args.diag_mix3:
@@ -596,6 +635,13 @@ def main():
         my_bytes = algorithmic_bytes(cnt, own_rows * width)
         dev_s = extent_ms * 1e-3
         traffic, traffic_src = pmc_traffic("crt_trace_kernel", sc.name, width, height) if (n == 1 and not args.shadows) else (None, None)
+        traffic_committed, traffic_live_note = traffic, None
+        if n == 1 and not args.shadows and not args.no_extras and not args.no_live_pmc and not args.diag_mix3:
+            # the contract's `traffic` measured by THIS run (the committed figure stays beside it as a cross-check)
+            live, note = live_pmc_traffic(sc.name, width, height)
+            traffic_live_note = note
+            if live is not None:
+                traffic, traffic_src = live, note
         hbm_achieved = None if traffic is None else traffic / dev_s / 1e9
         hbm_frac = None if hbm_achieved is None else hbm_achieved / HBM_PEAK_GBS
         num_cus = int(hip.crt_device_name().decode().split(",")[-1].split()[0])
@@ -663,8 +709,9 @@ def main():
                          "achieved": None if hbm_achieved is None else round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if hbm_frac is None else round(hbm_frac, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "frac_definition": "achieved / peak with achieved = `traffic` (FETCH_SIZE + WRITE_SIZE bytes per launch from the committed rocprofv3 --pmc passes of this "
-                                            "command: every byte that leaves L2, Infinity-Cache hits included, so an upper bound on HBM bytes) / device_time_per_launch_ms "
+                         "traffic_committed_profile": traffic_committed, "traffic_live_note": traffic_live_note,
+                         "frac_definition": "achieved / peak with achieved = `traffic` (FETCH_SIZE + WRITE_SIZE bytes per launch from rocprofv3 --pmc passes of this command -- measured by "
+                                            "two child runs of this very run when traffic_source says `live`, else the committed profile: every byte that leaves L2, Infinity-Cache hits included, so an upper bound on HBM bytes) / device_time_per_launch_ms "
                                             "(HIP events on the launch streams, this run). HBM is NOT what binds this kernel (dependent 64-B gathers through the CU's "
                                             "vector-memory path are: see `chain`, a model); SURVEY 8d's algorithmic bytes are a work measure (algorithmic_over_hbm_peak > 1)",
                          "error": roofline_error,

@@ -80,6 +80,10 @@ def test_single_gpu_line_carries_the_contract_and_the_round_3_objects():
     # the contract's HBM roofline: achieved = PMC traffic / this run's device time, never above the peak; everything else beside it
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and "frac_definition" in r and r["error"] is None
     assert r["traffic"] is None or (r["traffic"] > 0 and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] == r["hbm_frac"])
+    import shutil
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):      # the run measured its own HBM traffic: within 10 % of the committed passes
+        assert r["traffic_source"].startswith("live"), r["traffic_live_note"]
+        assert r["traffic_committed_profile"] is None or abs(r["traffic"] - r["traffic_committed_profile"]) <= 0.1 * r["traffic_committed_profile"]
     assert r["algorithmic_over_hbm_peak"] > 1.0                             # a work measure, flagged as such in frac_definition
     assert r["l2"] is None or (0 < r["l2"]["frac"] < 1.0 and r["l2"]["peak"] == 34500.0 and 0 < r["l1_hit"] < 1 and 0 < r["l2_hit"] < 1 and r["lds_instructions_per_launch"] > 0)
     assert r["chain"] is not None and r["chain"]["kind"].startswith("model") and r["chain"]["ceiling"] > 0 and 0.5 < r["chain"]["clock_ghz"] < 2.6
