@@ -257,6 +257,9 @@ def live_pmc_traffic(scene, width, height, timeout_s=150):
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
         return None, "rocprofv3 not found"
+    # this run is itself being profiled (a preloaded rocprofiler tool): a profiler inside a profiler is asking for trouble
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is already under a rocprofiler tool"
     kern = "crt_trace_kernel<false, false, false, false, false>"
     total, launches = 0.0, []
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
