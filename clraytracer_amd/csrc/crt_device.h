@@ -108,7 +108,7 @@ typedef CrtStackT<0> CrtStack;
 #define CRT_TILE 8        // 8x8 pixels per wave, Morton order inside
 
 // Node of the instance tree (TLAS): a world-space bounding sphere and two children; child bit 31 set = leaf, low bits =
-// instance index. Built on the host whenever instances are uploaded (crt_shim.hip, rebuild_instance_bounds).
+// instance index. Built on the host whenever instances are uploaded (crt_instances.h, rebuild_instance_master).
 struct CrtTlasNode { float4 sphere; uint32_t left, right, pad0, pad1; };
 #define CRT_TLAS_LEAF 0x80000000u
 #define CRT_TLAS_MIN_INSTANCES 64      // with fewer instances the linear sphere loop of candidate_mask is cheaper
@@ -462,7 +462,7 @@ struct Traversal {
 //     the cull is exact for ray origins with  |o| <= O_i = (w (sqrt(1.02 (1 - c1^2 / 2.8e-6)) - 1 - c1) - g4 tau) / (g4 kappa).
 // Rigid + uniform scale, instance centre p: kappa = 3, tau = sqrt 3 |p|: O_i ~ 13,800 w - 0.58 |p| -- a 1-unit instance may be
 // viewed from 13,800 units, a 1000-unit one from 1.4e7; kappa above ~470 (c1 > 2.3e-4) leaves no range at all.
-// (4) Outside the range the host turns the cull off (crt_shim.hip, rebuild_instance_master / render): an instance whose O_i is
+// (4) Outside the range the host turns the cull off (crt_instances.h rebuild_instance_master / crt_frame.h crt1_render): an instance whose O_i is
 // below the reach of bounce-ray origins (object-space hit points used as world origins, H6) is stored with r = -1 = never
 // culled; a frame whose camera, or a query whose farthest origin, lies beyond the smallest O_i of the remaining instances runs
 // with an all-never table (and the linear candidate loop). tests/test_gpu_cull_bound.py: instance scales 1e-3 ... 1e3,
@@ -701,9 +701,9 @@ __device__ __forceinline__ int sample_texture(const CrtTexture& tex, float u, fl
 }
 
 // kernel_main.cl:277-287
-__device__ __forceinline__ v3 raygen_dir(const CrtFrame& F, int i, int j)
+__device__ __forceinline__ v3 raygen_dir(const CrtFrame& F, int i, int j, int width, int height)
 {
-    float cx = (float)i / (float)F.width, cy = (float)j / (float)F.height;
+    float cx = (float)i / (float)width, cy = (float)j / (float)height;
     cx = cx * 2.0f - 1.0f;
     cy = cy * 2.0f - 1.0f;
     v3 t = matmul_xyz(F.invProj, cx, cy, 1.0f, 1.0f);
@@ -712,6 +712,8 @@ __device__ __forceinline__ v3 raygen_dir(const CrtFrame& F, int i, int j)
     v3 wv = matmul_xyz(F.invView, tx, ty, tz, tw);
     return normalize3(wv);
 }
+
+__device__ __forceinline__ v3 raygen_dir(const CrtFrame& F, int i, int j) { return raygen_dir(F, i, j, F.width, F.height); }
 
 // One bounce of kernel_main.cl:187-272 after the closest hit is known. Returns false when the
 // path terminated (miss -> skybox). On a hit, updates ray/energy/atmospheric/lightDir in place.

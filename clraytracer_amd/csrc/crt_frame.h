@@ -1,0 +1,690 @@
+// crt_frame.h -- one frame: feedback launch lists, the Trace launch by kernel structure, frame slots and events (Renderer.cpp:305-375), queries, reads, statistics
+// Part of the one translation unit crt_shim.hip (included there, in this order: crt_state.h, crt_instances.h, crt_upload.h,
+// crt_bvh_driver.h, crt_frame.h, crt_multidev.h); everything here has internal linkage.
+#pragma once
+namespace {
+
+// Event timing is read back lazily: when the slot is about to be reused (which also bounds the frames in flight to
+// one per slot), or when somebody asks. Synchronous frames are complete by then, so this never blocks them.
+int collect_set(EventSet& es)
+{
+    if (!es.pending) return CRT_OK;
+    hipEvent_t* ev = es.ev;
+    hipEvent_t traceStart = es.evRaygen ? ev[1] : ev[0], frameEnd = es.evPost ? ev[3] : ev[2];
+    HIPCHK(hipEventSynchronize(frameEnd));
+    float ms[4] = { 0, 0, 0, 0 };
+    HIPCHK(hipEventElapsedTime(&ms[0], ev[0], frameEnd));
+    if (es.evRaygen) HIPCHK(hipEventElapsedTime(&ms[1], ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms[2], traceStart, ev[2]));
+    if (es.evPost) HIPCHK(hipEventElapsedTime(&ms[3], ev[2], ev[3]));
+    for (int k = 0; k < 4; ++k) g.msSum[k] += (double)ms[k];
+    g.framesTimed++;
+    if (g.statStartValid && es.seq >= g.statStartSeq) {
+        float ext = 0;
+        HIPCHK(hipEventElapsedTime(&ext, g.statStart, frameEnd));
+        if ((double)ext > g.statExtent) g.statExtent = (double)ext;
+        if (es.seq == g.statStartSeq) g.statFirstMs = (double)ext;      // the first frame of the extent: fill time of the pipeline
+        if (g.frameLogN < 256) {
+            float st = 0;
+            if (hipEventElapsedTime(&st, g.statStart, ev[0]) == hipSuccess) { g.frameLog[2 * g.frameLogN] = (double)st; g.frameLog[2 * g.frameLogN + 1] = (double)ext; g.frameLogN++; }
+        }
+    }
+    if (es.seq >= g.msSeq) { memcpy(g.ms, ms, sizeof ms); g.msSeq = es.seq; }
+    if ((es.flags & CRT_RENDER_ASYNC) && !(es.flags & (CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS | CRT_RENDER_WRITE_RAYS))) g.pipelinedLatencyMs = ms[0];
+    if (es.flags & CRT_RENDER_COUNTERS) {
+        unsigned long long c[CRT_NUM_COUNTERS];
+        HIPCHK(hipMemcpy(c, g.counters, sizeof c, hipMemcpyDeviceToHost));
+        CrtCounters& o = g.lastCounters;
+        o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
+        o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
+        o.shadowRays = c[12]; o.shadowHits = c[13]; g.lastCulled = c[14];
+    }
+    es.pending = false;
+    return CRT_OK;
+}
+
+int collect_timing()
+{
+    for (int i = 0; i < g.nSlots; ++i) {
+        FrameSlot& fs = g.slot[i];
+        const int older = fs.es[0].seq <= fs.es[1].seq ? 0 : 1;
+        RCCHK(collect_set(fs.es[older]));
+        RCCHK(collect_set(fs.es[older ^ 1]));
+    }
+    return CRT_OK;
+}
+
+// Feedback launch lists for the megakernel (lane_pixel / crt_order_kernel). Buffers follow the frame geometry; a
+// change of geometry resets to the identity order. The previous frame's per-tile costs are turned into this frame's
+// lists (and the costs zeroed) by a sort that is queued right AFTER the previous frame's last kernel and its end
+// event (sort_for_next_frame), so it runs while the host is between two crt1_render calls and is off the frame's
+// critical path (it used to open every frame: 10 us + a launch gap of a 0.5 ms synchronous frame).
+// this frame's per-tile costs -> the next frame's lists; with g.costSpread > 0 a tile is ranked by its neighbours' costs too
+static void launch_order_kernel(const CrtFrame& F, FrameSlot& fs, bool pipelined, bool noSplit = false)
+{
+    const uint32_t* key = fs.cost;
+    if (g.costSpread > 0.0f && g.viewMoved) {
+        uint32_t* k2 = fs.cost + fs.orderCap;                   // second half of the cost allocation
+        crt_cost_spread_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, fs.stream>>>(fs.cost, k2, F.slotsPerXcd, F.tilesX, g.costSpread);
+        key = k2;
+    }
+    crt_order_kernel<<<8, 1024, 0, fs.stream>>>(fs.cost, key, fs.order, fs.len, F.slotsPerXcd, F.listCap, noSplit ? 0u : (uint32_t)(pipelined ? g.maxSplitPipelined : g.maxSplit),
+                                                 (pipelined ? g.splitBetaAsync : g.splitBeta) / (float)((g.numCUs / 8) * 4 * CRT_WAVES_PER_SIMD));
+}
+
+static int prepare_launch_lists(CrtFrame& F, unsigned& grid, FrameSlot& fs, bool pipelined, bool noSplit = false)
+{
+    const int key[6] = { g.width, g.height, g.bandRows, g.rank, g.nRanks, F.slotsPerXcd };
+    F.listCap = F.slotsPerXcd + 3 * CRT_MAX_SPLIT;
+    const size_t need = (size_t)8 * (size_t)F.listCap;
+    if (need > fs.orderCap) {
+        if (fs.order) (void)hipFree(fs.order);
+        if (fs.len) (void)hipFree(fs.len);
+        if (fs.cost) (void)hipFree(fs.cost);
+        fs.order = nullptr; fs.len = nullptr; fs.cost = nullptr; fs.orderCap = 0;
+        HIPCHK(hipMalloc(&fs.order, sizeof(uint32_t) * need));
+        HIPCHK(hipMalloc(&fs.len, sizeof(uint32_t) * 8));
+        HIPCHK(hipMalloc(&fs.cost, sizeof(uint32_t) * need * 2));        // costs, then the sort keys derived from them
+        fs.orderCap = need; fs.orderSlots = -1;
+    }
+    if (fs.orderSlots != F.slotsPerXcd || memcmp(key, fs.orderKey, sizeof key) != 0) {
+        HIPCHK(hipMemsetAsync(fs.cost, 0, sizeof(uint32_t) * need, fs.stream));
+        crt_identity_order_kernel<<<(8 * F.slotsPerXcd + 255) / 256, 256, 0, fs.stream>>>(fs.order, fs.len, F.slotsPerXcd, F.listCap);
+        fs.orderSlots = F.slotsPerXcd; memcpy(fs.orderKey, key, sizeof key);
+    } else if (!fs.listsReady) {
+        launch_order_kernel(F, fs, pipelined, noSplit);
+    }
+    fs.listsReady = false;
+    HIPCHK(hipGetLastError());
+    F.order = fs.order; F.listLen = fs.len; F.cost = fs.cost;
+    grid = 8u * (unsigned)F.listCap;
+    return CRT_OK;
+}
+
+// Queued behind a frame's last kernel: this frame's costs -> the next frame's lists (same geometry assumed; a change is
+// caught by the key in prepare_launch_lists, which then starts from the identity order again).
+static int sort_for_next_frame(const CrtFrame& F, FrameSlot& fs, bool pipelined, bool noSplit = false)
+{
+    launch_order_kernel(F, fs, pipelined, noSplit);
+    HIPCHK(hipGetLastError());
+    fs.listsReady = true;
+    return CRT_OK;
+}
+
+// The Trace launch(es) of one frame, by kernel structure (default: megakernel with feedback launch lists).
+// `out`: the frame the launch writes (the slot's frame, or its unfiltered copy when FXAA follows).
+// *epilogueApplied: the launch was the default megakernel, which applies F.epilogue (RGBA8 target / PostProcess) itself
+static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsigned grid, FrameSlot& fs, float4* out, bool* epilogueApplied, bool refill = false)
+{
+    *epilogueApplied = false;
+    const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
+    if (count) HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), fs.stream));
+    if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
+        const size_t need = (16 + (size_t)grid * 8) * sizeof(unsigned long long);
+        if (need > g.stampBytes) {
+            if (g.stamps) (void)hipFree(g.stamps);
+            g.stamps = nullptr; g.stampBytes = 0;
+            HIPCHK(hipMalloc(&g.stamps, need));
+            g.stampBytes = need;
+        }
+        g.stampWaves = grid;
+        HIPCHK(hipMemsetAsync(g.stamps, 0, need, fs.stream));
+        if (refill && g.refill == 2) crt_trace_block_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps, fs.blockQueue);
+        else if (refill) crt_trace_refill_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps);
+        else crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps);
+        *epilogueApplied = true;                           // the same kernel template: F.epilogue is applied there
+    } else if (refill) {                                   // in-tile lane refill (crt_refill.h); F counts blocks, not tiles
+        *epilogueApplied = true;
+        if (g.refill == 2) {
+            if (count) crt_trace_block_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, fs.blockQueue);
+            else crt_trace_block_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, fs.blockQueue);
+        } else if (count) crt_trace_refill_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters);
+        else crt_trace_refill_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters);
+    } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
+        const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
+        const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
+        HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), fs.stream));
+        if (count) {
+            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
+        } else {
+            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
+            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
+        }
+    } else {
+        // default megakernel: <COUNT, STAMP, SHADOW, TLAS, REFRACT>
+        *epilogueApplied = true;
+        const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, refract = (flags & CRT_RENDER_REFRACTION) != 0;
+        // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
+        const bool tlas = S.tlasNodes > 0 && (g.forceTlas >= 0 ? (g.forceTlas != 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh));      // (S.tlasNodes = 0: no tree, or a frame without the cull)
+#define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) crt_trace_kernel<C_, false, S_, T_, R_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters)
+#define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) CRT_LAUNCH_TRACE3(C_, S_, T_, true); else CRT_LAUNCH_TRACE3(C_, S_, T_, false); } while (0)
+#define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) CRT_LAUNCH_TRACE2(C_, S_, true); else CRT_LAUNCH_TRACE2(C_, S_, false); } while (0)
+        if (count) { if (shadow) CRT_LAUNCH_TRACE(true, true); else CRT_LAUNCH_TRACE(true, false); }
+        else       { if (shadow) CRT_LAUNCH_TRACE(false, true); else CRT_LAUNCH_TRACE(false, false); }
+#undef CRT_LAUNCH_TRACE
+#undef CRT_LAUNCH_TRACE2
+#undef CRT_LAUNCH_TRACE3
+    }
+    HIPCHK(hipGetLastError());
+    return CRT_OK;
+}
+
+// one wave that occupies its stream for `ticks` periods of the 100 MHz real-time counter (start-up stagger, see State::burstFrames)
+__global__ void crt_delay_kernel(unsigned long long ticks)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long guard = 0;
+    while (__builtin_amdgcn_s_memrealtime() - r0 < ticks && guard < (1ull << 22)) { __builtin_amdgcn_s_sleep(16); ++guard; }
+}
+
+// In a multi-device session the dispatcher (crt_render) decides once per frame what every device must agree on and hands it
+// to each device's crt1_render: the frame slot (so a device that owned no rows of some frame, or failed one, cannot fall out
+// of step with the primary's slot rotation) and whether the call may return before the device has finished (secondaries
+// never wait on the host: the primary's end-of-frame event waits for their partDone events, which is what gives a
+// synchronous N-device frame the duration of the longest share instead of the sum of two).
+struct RenderPlan { int slot; bool noHostWait; };
+
+int crt1_render(const CrtTraceArgs* args, const float invView[16], const float invProj[16], int flags, const RenderPlan* plan = nullptr)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!args || !invView || !invProj) return CRT_E_BAD_ARGUMENT;
+    if (args->numMeshes > CRT_MAX_INSTANCES) return CRT_E_OUT_OF_RANGE;
+    if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
+    int rc = CRT_OK;
+    CrtFrame F; fill_frame(F, args, invView, invProj);
+    if (F.gridBlocks == 0) {
+        // a device that owns no rows of this frame still takes part in the frame's hand-shake: its "bands have arrived"
+        // event is recorded on the planned slot so the primary's wait refers to this frame, not to an older one
+        if (plan && g.groupSize > 1 && g.primary != G && plan->slot >= 0 && plan->slot < g.nSlots) {
+            FrameSlot& efs = g.slot[plan->slot];
+            if (plan->slot != 0) g.othersBusy = true;
+            HIPCHK(hipEventRecord(efs.partDone, efs.stream));
+        }
+        return CRT_OK;
+    }
+    unsigned grid = (unsigned)F.gridBlocks;
+
+    // Slot choice: plain ASYNC frames of the default kernel rotate over the frame slots so consecutive frames
+    // overlap (each slot has its own stream, output buffer and launch lists). Everything else -- synchronous frames,
+    // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
+    const bool variant = g.wavefront != 0;
+    if ((flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION)) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
+    // CRT_KERNEL=refill: the frames the refill kernel supports (one 64-bit candidate mask, no shadow rays / refraction / instance tree / diagnostics)
+    const bool refill = g.refill && !(flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION | CRT_RENDER_DIAG_MIX3))
+                     && args->numMeshes <= 64u && g.forceTlas != 1;
+    const bool fxaa = (flags & CRT_RENDER_FXAA) != 0;
+    if (fxaa && g.groupSize <= 1 && g.nRanks > 1) return CRT_E_UNSUPPORTED;                  // the filter reads across band edges
+    const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
+                        && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
+    int slot = 0;
+    if (plan) {                              // multi-device session: the dispatcher chose the slot for every device
+        slot = pipelined ? plan->slot : 0;
+        if (slot < 0 || slot >= g.nSlots) return CRT_E_BAD_ARGUMENT;
+        if (!pipelined) { rc = quiesce(); if (rc) return rc; }
+    } else if (pipelined) slot = (int)(g.asyncSeq++ % (unsigned)g.nSlots);
+    else { rc = quiesce(); if (rc) return rc; }
+    FrameSlot& fs = g.slot[slot];
+    EventSet& es = fs.es[fs.frames & 1u];
+    rc = collect_set(es);                    // waits for the frame two back on this slot: at most two queued per slot
+    if (rc) return rc;
+    if (flags & CRT_RENDER_COUNTERS) { rc = collect_timing(); if (rc) return rc; }
+    if (slot != 0) g.othersBusy = true;
+    rc = ensure_slot_instances(fs);          // this slot's instance tables, refreshed on its stream if an upload happened since
+    if (rc) return rc;
+    CrtDevScene S;
+    // Feedback launch lists serve synchronous frames, whose end is decided by their slowest waves. With frames in flight the
+    // tail is hidden by the next frame and the lists only cost (cost atomics, the sort launch, quadrant waves at a quarter
+    // of the lane utilisation): 7.58 with, 7.72 Gray/s without on multi-1M -> pipelined frames use the plain row-interleaved order.
+    const bool mix3 = (flags & CRT_RENDER_DIAG_MIX3) != 0;
+    if (mix3) {
+        if (pipelined || variant || g.groupSize > 1 || (flags & (CRT_RENDER_STAMPS | CRT_RENDER_WRITE_RAYS | CRT_RENDER_FXAA))) return CRT_E_UNSUPPORTED;
+        // three copies of the plain row-interleaved order, copy j starting a third of the XCD's list later: entry 3 i + j = tile (i + j S / 3) mod S
+        const int S3 = 3 * F.slotsPerXcd;
+        if ((size_t)8 * S3 > fs.mixCap) {
+            HIPCHK(hipStreamSynchronize(fs.stream));
+            if (fs.mixOrder) (void)hipFree(fs.mixOrder);
+            if (fs.mixLen) (void)hipFree(fs.mixLen);
+            fs.mixOrder = nullptr; fs.mixLen = nullptr; fs.mixCap = 0; fs.mixSlots = -1;
+            HIPCHK(hipMalloc(&fs.mixOrder, sizeof(uint32_t) * 8 * (size_t)S3));
+            HIPCHK(hipMalloc(&fs.mixLen, sizeof(uint32_t) * 8));
+            fs.mixCap = (size_t)8 * S3;
+        }
+        if (fs.mixSlots != F.slotsPerXcd) {
+            std::vector<uint32_t> h((size_t)8 * S3), len(8, (uint32_t)S3);
+            for (int x = 0; x < 8; ++x)
+                for (int i = 0; i < F.slotsPerXcd; ++i)
+                    for (int j = 0; j < 3; ++j) h[(size_t)x * S3 + 3 * i + j] = (uint32_t)((i + j * (F.slotsPerXcd / 3)) % F.slotsPerXcd);
+            HIPCHK(hipMemcpyAsync(fs.mixOrder, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, fs.stream));
+            HIPCHK(hipMemcpyAsync(fs.mixLen, len.data(), 8 * sizeof(uint32_t), hipMemcpyHostToDevice, fs.stream));
+            HIPCHK(hipStreamSynchronize(fs.stream));      // the host vectors go out of scope
+            fs.mixSlots = F.slotsPerXcd;
+        }
+        F.order = fs.mixOrder; F.listLen = fs.mixLen; F.listCap = S3; F.cost = nullptr;
+        grid = 8u * (unsigned)S3;
+    } else
+    if (g.feedback && !g.wavefront && !refill && (!pipelined || g.feedbackAsync)) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
+    // CRT_KERNEL=refill: the Trace launch (and its feedback lists) count BLOCKS of CRT_REFILL_TILES tiles where F counts tiles
+    CrtFrame FB = F; unsigned gridB = grid;
+    if (refill) {
+        const int tiles = g.refill == 2 ? CRT_BLOCK_TILES : CRT_REFILL_TILES;
+        FB.tilesX = (F.tilesX + tiles - 1) / tiles;
+        FB.gridBlocks = ((F.ownedTileRows + 7) / 8) * 8 * FB.tilesX;
+        FB.slotsPerXcd = FB.gridBlocks / 8; FB.listCap = FB.slotsPerXcd;
+        gridB = (unsigned)FB.gridBlocks;
+        if (g.feedback && (!pipelined || g.feedbackAsync)) { rc = prepare_launch_lists(FB, gridB, fs, pipelined, true); if (rc) return rc; }
+        if (g.refill == 2) {
+            const size_t need = (size_t)FB.gridBlocks * CRT_BLOCK_PIXELS;
+            if (need > fs.blockQueueCap) {
+                HIPCHK(hipStreamSynchronize(fs.stream));
+                if (fs.blockQueue) (void)hipFree(fs.blockQueue);
+                fs.blockQueue = nullptr; fs.blockQueueCap = 0;
+                HIPCHK(hipMalloc(&fs.blockQueue, need * sizeof(CrtBounceRay)));
+                fs.blockQueueCap = need;
+            }
+        }
+    }
+    {   // overflow blocks: one per workgroup of the largest launch of this frame (wavefront: the bounce launch may be larger)
+        size_t blocks = grid;
+        if (g.wavefront) { const size_t g2 = ((size_t)F.ownedTileRows * CRT_TILE * (size_t)F.width + CRT_BLOCK - 1) / CRT_BLOCK; if (g2 > blocks) blocks = g2; }
+        rc = ensure_overflow(fs, blocks); if (rc) return rc;
+    }
+    fill_scene(S, args->numMeshes, fs, beyond_cull_range(sqrt((double)args->cameraPos[0] * args->cameraPos[0] + (double)args->cameraPos[1] * args->cameraPos[1] + (double)args->cameraPos[2] * args->cameraPos[2])));
+
+    // events: [0] frame start, [1] Trace start, [2] Trace end, [3] end of PostProcess = frame end.
+    // A plain frame records only two (RayGen is fused, PostProcess off): [0] == [1], [2] == [3].
+    if (g.statStartArmed) {                  // first frame since the statistics were reset: start of the extent
+        HIPCHK(hipEventRecord(g.statStart, fs.stream));
+        g.statStartArmed = false; g.statStartValid = true; g.statStartSeq = g.frameSeq + 1; g.statExtent = 0; g.statFirstMs = 0; g.frameLogN = 0;
+    }
+    if (pipelined) {
+        // first frame of this slot in a burst that starts from an idle device: hold it back so the slots do not run in lockstep
+        const unsigned k = g.burstFrames++;
+        // (automatic only with up to three slots: with eight -- a rank's small share of a tiled frame, where one frame cannot fill the
+        // GPU and the slots exist to run many at once -- the ramp costs more than the coinciding tails: 83.2 -> 74.6 Gray/s predicted at N = 8)
+        if (k > 0 && k < (unsigned)g.nSlots && g.staggerUs != 0 && (g.staggerUs > 0 || (g.nSlots <= 3 && g.prevBurstFrames > (unsigned)g.nSlots))) {
+            double step = g.staggerUs > 0 ? (double)g.staggerUs : (double)g.pipelinedLatencyMs * 1e3 / (double)g.nSlots;
+            if (step > 500.0) step = 500.0;                      // a stale or foreign latency must not stall a burst
+            const double us = step * k;
+            if (us >= 5.0) { crt_delay_kernel<<<1, 64, 0, fs.stream>>>((unsigned long long)(us * 100.0)); HIPCHK(hipGetLastError()); g.staggeredFrames++; }
+        }
+    } else { if (g.burstFrames) g.prevBurstFrames = g.burstFrames; g.burstFrames = 0; }
+    es.evRaygen = (flags & CRT_RENDER_WRITE_RAYS) != 0;
+    es.evPost = (flags & (CRT_RENDER_POSTPROCESS | CRT_RENDER_UNORM8 | CRT_RENDER_FXAA)) != 0;
+    HIPCHK(hipEventRecord(es.ev[0], fs.stream));
+    if (es.evRaygen) {
+        crt_raygen_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, g.rays);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(es.ev[1], fs.stream));
+    }
+    // upstream's per-pixel stages behind Trace (its RGBA8 render target, PostProcess) ride in the Trace kernel's epilogue
+    // unless a kernel variant without the epilogue is selected. FXAA sits between them and reads neighbours: on one device
+    // Trace then writes the slot's second buffer (its pixels already through the RGBA8 target) and the filter writes the
+    // frame, applying PostProcess and the final RGBA8 store in ITS epilogue -- two launches, no copy.
+    const bool unorm = (flags & CRT_RENDER_UNORM8) != 0, post = (flags & CRT_RENDER_POSTPROCESS) != 0;
+    const bool fxaaLocal = fxaa && g.groupSize <= 1;
+    const size_t framePixels = (size_t)g.width * (size_t)g.height;
+    if (fxaa && !(g.groupSize > 1 && g.primary != G) && fs.auxPixels < framePixels) {
+        HIPCHK(hipStreamSynchronize(fs.stream));
+        if (fs.aux) (void)hipFree(fs.aux);
+        fs.aux = nullptr; fs.auxPixels = 0;
+        HIPCHK(hipMalloc(&fs.aux, framePixels * sizeof(float4)));
+        fs.auxPixels = framePixels;
+    }
+    if (!fxaa) F.epilogue = (unorm ? CRT_EPILOGUE_QUANTIZE : 0u) | (post ? CRT_EPILOGUE_POST : 0u);
+    else if (fxaaLocal) F.epilogue = unorm ? CRT_EPILOGUE_QUANTIZE : 0u;
+    // a read-back of the RGBA8 frame: the kernel that stores the final pixel stores its four bytes too (one device; a
+    // multi-device session packs the gathered frame on its first device)
+    const bool packInKernel = unorm && (flags & CRT_RENDER_READBACK) && g.groupSize <= 1;
+    if (packInKernel && framePixels * 4 > fs.packCap) {
+        HIPCHK(hipStreamSynchronize(fs.stream));
+        if (fs.packBuf) (void)hipFree(fs.packBuf);
+        fs.packBuf = nullptr; fs.packCap = 0;
+        HIPCHK(hipMalloc(&fs.packBuf, framePixels * 4));
+        fs.packCap = framePixels * 4;
+    }
+    if (packInKernel && !fxaa) F.packOut = fs.packBuf;
+    bool fused = false;
+    if (refill) { FB.epilogue = F.epilogue; FB.packOut = F.packOut; }
+    rc = launch_trace(S, refill ? FB : F, flags, refill ? gridB : grid, fs, fxaaLocal ? fs.aux : fs.out, &fused, refill);
+    if (rc) return rc;
+    // in-process multi-GPU, primary device: the frame is complete when every secondary's bands have arrived -- its last
+    // event is recorded behind waits for their partDone events (recorded before this call: the dispatcher submits the
+    // secondaries first)
+    const bool isPrimary = g.groupSize > 1 && g.primary == G, isSecondary = g.groupSize > 1 && g.primary != G;
+    auto wait_for_parts = [&]() -> int {
+        for (int d = 1; d < g.groupSize; ++d) HIPCHK(hipStreamWaitEvent(fs.stream, g.group[d]->slot[slot].partDone, 0));
+        return CRT_OK;
+    };
+    if (isPrimary && !es.evPost) RCCHK(wait_for_parts());
+    HIPCHK(hipEventRecord(es.ev[2], fs.stream));
+    if (es.evPost) {
+        // upstream: Trace write_imagef's into an RGBA8 texture, PostProcess read_imagef's it back and write_imagef's again
+        if (!fxaa) {
+            if (!fused) {
+                if (unorm) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+                if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+                if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+                HIPCHK(hipGetLastError());
+            }
+            if (isPrimary) RCCHK(wait_for_parts());
+        } else if (!isSecondary) {
+            // FXAA reads up to 5 pixels around its own in the Trace result, so it runs on the whole frame: a multi-device
+            // session gathers the raw bands first (the secondaries skip their per-pixel stages) and its first device filters
+            if (isPrimary) RCCHK(wait_for_parts());
+            CrtFrame FF = F;                                // every tile row, plain order
+            FF.order = nullptr; FF.cost = nullptr; FF.listLen = nullptr;
+            FF.rank = 0; FF.nRanks = 1;
+            FF.ownedTileRows = (g.height + CRT_TILE - 1) / CRT_TILE;
+            FF.gridBlocks = ((FF.ownedTileRows + 7) / 8) * 8 * FF.tilesX;
+            FF.slotsPerXcd = FF.gridBlocks / 8; FF.listCap = FF.slotsPerXcd;
+            const unsigned gridAll = (unsigned)FF.gridBlocks;
+            if (fxaaLocal) {
+                if (unorm && !fused) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.aux);
+            } else {
+                if (unorm) crt_quantize_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.out);
+                HIPCHK(hipMemcpyAsync(fs.aux, fs.out, framePixels * sizeof(float4), hipMemcpyDeviceToDevice, fs.stream));
+            }
+            FF.epilogue = (unorm ? CRT_EPILOGUE_QUANTIZE : 0u) | (post ? CRT_EPILOGUE_POST : 0u);
+            FF.packOut = packInKernel ? fs.packBuf : nullptr;
+            crt_fxaa_kernel<<<gridAll, CRT_BLOCK, 0, fs.stream>>>(FF, fs.aux, fs.out);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(es.ev[3], fs.stream));
+    }
+    if (isSecondary) {
+        // gather: this device's bands go into the primary's frame of the same slot (peer copy over xGMI), once the primary
+        // is done with whatever the slot's previous frame still had queued (its read-back)
+        FrameSlot& pfs = g.primary->slot[slot];
+        HIPCHK(hipStreamWaitEvent(fs.stream, pfs.slotDone, 0));
+        RCCHK(copy_owned_rows_async(pfs.out, fs.out, 16, hipMemcpyDeviceToDevice, fs.stream));
+        HIPCHK(hipEventRecord(fs.partDone, fs.stream));
+    }
+    g.cur = slot;
+    es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
+    const bool sorted = (refill ? FB.order : F.order) != nullptr && !mix3;
+    if (sorted) {
+        // did the view change since the last sorted frame? (camera matrices and position, instance tables)
+        float view[35];
+        memcpy(view, F.invView, 64); memcpy(view + 16, F.invProj, 64); memcpy(view + 32, F.camPos, 12);
+        g.viewMoved = memcmp(view, g.lastView, sizeof view) != 0 || g.lastViewInst != g.instVersion;
+        memcpy(g.lastView, view, sizeof view); g.lastViewInst = g.instVersion;
+        rc = sort_for_next_frame(refill ? FB : F, fs, pipelined, refill); if (rc) return rc;
+    }
+    if (flags & CRT_RENDER_READBACK) {
+        // the frame travels to pinned host memory behind its own kernels; the other slots' frames keep the GPU busy meanwhile
+        const size_t pixels = (size_t)g.width * (size_t)g.height;
+        const bool bytes8 = (flags & CRT_RENDER_UNORM8) != 0;
+        const size_t bytes = pixels * (bytes8 ? 4 : 16);
+        if (bytes > fs.hostCap) {
+            if (fs.hostBuf) (void)hipHostFree(fs.hostBuf);
+            fs.hostBuf = nullptr; fs.hostCap = 0;
+            HIPCHK(hipHostMalloc(&fs.hostBuf, bytes, hipHostMallocDefault));
+            fs.hostCap = bytes;
+        }
+        if (!fs.copied) HIPCHK(hipEventCreateWithFlags(&fs.copied, hipEventDisableTiming));
+        const void* src = fs.out;
+        if (bytes8) {
+            if (pixels * 4 > fs.packCap) {
+                if (fs.packBuf) (void)hipFree(fs.packBuf);
+                fs.packBuf = nullptr; fs.packCap = 0;
+                HIPCHK(hipMalloc(&fs.packBuf, pixels * 4));
+                fs.packCap = pixels * 4;
+            }
+            const bool packed = packInKernel && (fxaa || fused);     // the Trace (or FXAA) kernel stored the bytes already
+            if (!packed) crt_pack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, fs.stream>>>(fs.out, fs.packBuf, pixels);
+            HIPCHK(hipGetLastError());
+            src = fs.packBuf;
+        }
+        // only the rows this rank renders travel (the host buffer keeps the full-frame layout)
+        RCCHK(copy_owned_rows_async(fs.hostBuf, src, bytes8 ? 4 : 16, hipMemcpyDeviceToHost, fs.stream, isPrimary));
+        HIPCHK(hipEventRecord(fs.copied, fs.stream));
+        fs.hostBytes = bytes; g.readbackRing[g.readbackCount++ % CRT_MAX_FRAMES_IN_FLIGHT] = slot;
+    }
+    if (isPrimary) HIPCHK(hipEventRecord(fs.slotDone, fs.stream));
+    // the reference's clFinish (Renderer.cpp:367): wait for the frame's end event -- the sort for the next frame that is
+    // queued behind it needs no waiting for
+    if (!(flags & CRT_RENDER_ASYNC) && !(plan && plan->noHostWait)) HIPCHK(hipEventSynchronize(es.evPost ? es.ev[3] : es.ev[2]));
+    return CRT_OK;
+}
+
+// Whether a frame with these flags rotates over the frame slots (the rule of crt1_render, for the dispatcher)
+static bool frame_is_pipelined(int flags)
+{
+    return (flags & CRT_RENDER_ASYNC) && !g.wavefront && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
+}
+
+// Diagnostic: the shader clock under whatever load the device carries right now. One wave per XCD spins for `micros`
+// microseconds of the 100 MHz real-time counter and reports delta s_memtime / delta s_memrealtime (MI355X_MICROARCH.md, DVFS
+// item 6); runs on a stream of its own, next to the frames in flight.
+__global__ void crt_clock_probe_kernel(unsigned long long ticks, double* __restrict__ out)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0, guard = 0;
+    while (r1 - r0 < ticks && guard < (1ull << 24)) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); ++guard; }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) out[blockIdx.x] = r1 > r0 ? (double)(c1 - c0) / (double)(r1 - r0) * 0.1 : 0.0;
+}
+
+int crt1_debug_measure_clock(int micros, double* ghz)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!ghz || micros < 1 || micros > 100000) return CRT_E_BAD_ARGUMENT;
+    double* d = nullptr; hipStream_t st = nullptr;
+    HIPCHK(hipMalloc(&d, 8 * sizeof(double)));
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    double h[8] = { 0 };
+    if (e == hipSuccess) {
+        crt_clock_probe_kernel<<<8, 64, 0, st>>>((unsigned long long)micros * 100ull, d);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(d);
+    if (e != hipSuccess) return (int)e;
+    double sum = 0; int n = 0;
+    for (double v : h) if (v > 0.0) { sum += v; ++n; }
+    *ghz = n ? sum / n : 0.0;
+    return CRT_OK;
+}
+
+int crt1_sync(void)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    return sync_all();
+}
+
+int crt1_query_hits(const float* origins, const float* dirs, int n, uint32_t numInstances, CrtRayHit* out)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (n <= 0) return CRT_OK;
+    if (!origins || !dirs || !out || numInstances > CRT_MAX_INSTANCES) return CRT_E_BAD_ARGUMENT;
+    if (!g.sceneValid) return CRT_E_BAD_ARGUMENT;
+    int rc = collect_timing();
+    if (rc) return rc;
+    RCCHK(quiesce());
+    const size_t rayBytes = sizeof(float) * 3 * (size_t)n, need = rayBytes * 2 + sizeof(CrtRayHit) * (size_t)n;
+    if (need > g.queryBytes) {
+        if (g.queryBuf) (void)hipFree(g.queryBuf);
+        g.queryBuf = nullptr; g.queryBytes = 0;
+        HIPCHK(hipMalloc(&g.queryBuf, need));
+        g.queryBytes = need;
+    }
+    float* dO = static_cast<float*>(g.queryBuf);
+    float* dD = dO + 3 * (size_t)n;
+    CrtRayHit* dH = reinterpret_cast<CrtRayHit*>(dD + 3 * (size_t)n);
+    HIPCHK(hipMemcpyAsync(dO, origins, rayBytes, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(dD, dirs, rayBytes, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), g.stream));
+    FrameSlot& fs = g.slot[0];
+    RCCHK(ensure_slot_instances(fs));
+    RCCHK(ensure_overflow(fs, (size_t)((n + CRT_BLOCK - 1) / CRT_BLOCK)));
+    double farthest2 = 0.0;      // the cull is proven for origins up to State::cullOriginLimit from the world origin
+    for (int k = 0; k < n; ++k) {
+        const double x = origins[3 * k], y = origins[3 * k + 1], z = origins[3 * k + 2], d2 = x * x + y * y + z * z;
+        if (!(d2 <= farthest2)) farthest2 = d2;      // (NaN sticks)
+    }
+    CrtDevScene S; fill_scene(S, numInstances, fs, beyond_cull_range(sqrt(farthest2)));
+    const bool tlas = S.tlasNodes > 0 && (g.forceTlas >= 0 ? (g.forceTlas != 0 && numInstances <= g.instHigh) : (numInstances > CRT_TLAS_MIN_INSTANCES && numInstances <= g.instHigh));
+    if (tlas) crt_query_kernel<true><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
+    else crt_query_kernel<false><<<(unsigned)((n + CRT_BLOCK - 1) / CRT_BLOCK), CRT_BLOCK, 0, g.stream>>>(S, dO, dD, n, dH, g.counters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dH, sizeof(CrtRayHit) * (size_t)n, hipMemcpyDeviceToHost, g.stream));
+    unsigned long long c[CRT_NUM_COUNTERS];
+    HIPCHK(hipMemcpyAsync(c, g.counters, sizeof c, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    CrtCounters& o = g.lastCounters;
+    o.rays = c[0]; o.primary = c[1]; o.secondary = c[2]; o.hits = c[3]; o.misses = c[4]; o.traversals = c[5];
+    o.pops = c[6]; o.innerVisits = c[7]; o.triTests = c[8]; o.capHits = c[9]; o.stackOverflows = c[10]; o.maxStack = c[11];
+    o.shadowRays = c[12]; o.shadowHits = c[13]; g.lastCulled = c[14];
+    return CRT_OK;
+}
+
+int crt1_read_output(float* dst, size_t floats)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!dst || floats != (size_t)g.width * (size_t)g.height * 4) return CRT_E_BAD_ARGUMENT;
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, g.slot[g.cur].out, floats * sizeof(float), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt1_read_output_rows(float* dst, int row0, int rows)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!dst || row0 < 0 || rows < 0 || row0 + rows > g.height) return CRT_E_BAD_ARGUMENT;
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, g.slot[g.cur].out + (size_t)row0 * (size_t)g.width, (size_t)rows * (size_t)g.width * sizeof(float4), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt1_read_output_rgba8(uint8_t* dst, size_t bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    const size_t pixels = (size_t)g.width * (size_t)g.height;
+    if (!dst || bytes != pixels * 4) return CRT_E_BAD_ARGUMENT;
+    RCCHK(sync_all());
+    if (pixels * 4 > g.queryBytes) {                       // shares the query scratch buffer
+        if (g.queryBuf) (void)hipFree(g.queryBuf);
+        g.queryBuf = nullptr; g.queryBytes = 0;
+        HIPCHK(hipMalloc(&g.queryBuf, pixels * 4));
+        g.queryBytes = pixels * 4;
+    }
+    crt_pack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, g.stream>>>(g.slot[g.cur].out, static_cast<uint32_t*>(g.queryBuf), pixels);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dst, g.queryBuf, pixels * 4, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return CRT_OK;
+}
+
+int crt1_map_host_frame_back(int framesBack, const void** ptr, size_t* bytes)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    // a pipelined frame's copy lives in its slot until the slot is reused: the last nSlots READBACK frames are reachable
+    if (!ptr || framesBack < 0 || (unsigned)framesBack >= g.readbackCount || framesBack >= g.nSlots) return CRT_E_BAD_ARGUMENT;
+    const int slot = g.readbackRing[(g.readbackCount - 1u - (unsigned)framesBack) % CRT_MAX_FRAMES_IN_FLIGHT];
+    for (int k = 0; k < framesBack; ++k)      // a later frame on the same slot (synchronous frames all use slot 0) has replaced it
+        if (g.readbackRing[(g.readbackCount - 1u - (unsigned)k) % CRT_MAX_FRAMES_IN_FLIGHT] == slot) return CRT_E_BAD_ARGUMENT;
+    FrameSlot& fs = g.slot[slot];
+    HIPCHK(hipEventSynchronize(fs.copied));
+    *ptr = fs.hostBuf;
+    if (bytes) *bytes = fs.hostBytes;
+    return CRT_OK;
+}
+
+int crt1_map_host_frame(const void** ptr, size_t* bytes) { return crt1_map_host_frame_back(0, ptr, bytes); }
+
+int crt1_read_rays(float* dst, size_t floats)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!dst || floats != (size_t)g.width * (size_t)g.height * 3) return CRT_E_BAD_ARGUMENT;
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, g.rays, floats * sizeof(float), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+void* crt1_output_device_ptr(void) { return g.initialized ? (void*)g.slot[g.cur].out : nullptr; }
+
+float crt1_last_kernel_ms(int which)
+{
+    if (!g.initialized || which < 0 || which > 3) return -1.0f;
+    if (collect_timing() != CRT_OK) return -1.0f;
+    return g.ms[which];
+}
+
+int crt1_frame_time_stats(CrtFrameStats* out, int reset)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    RCCHK(collect_timing());
+    if (out) {
+        out->frames = g.framesTimed;
+        for (int k = 0; k < 4; ++k) out->sumMs[k] = g.msSum[k];
+        out->extentMs = g.statExtent;
+        out->firstFrameMs = g.statFirstMs;
+    }
+    if (reset) {
+        for (int k = 0; k < 4; ++k) g.msSum[k] = 0.0;
+        g.framesTimed = 0; g.statExtent = 0; g.statFirstMs = 0; g.statStartArmed = true; g.statStartValid = false;
+    }
+    return CRT_OK;
+}
+
+int crt1_debug_read_frame_times(double* dst, size_t maxFrames, size_t* numFrames)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!numFrames) return CRT_E_BAD_ARGUMENT;
+    RCCHK(collect_timing());
+    *numFrames = g.frameLogN;
+    if (dst) memcpy(dst, g.frameLog, sizeof(double) * 2 * (maxFrames < g.frameLogN ? maxFrames : g.frameLogN));
+    return CRT_OK;
+}
+
+int crt1_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!numWaves) return CRT_E_BAD_ARGUMENT;
+    *numWaves = g.stampWaves;
+    if (!dst || !g.stamps) return CRT_OK;
+    const size_t n = maxWaves < g.stampWaves ? maxWaves : g.stampWaves;
+    RCCHK(sync_all());
+    HIPCHK(hipMemcpy(dst, g.stamps + 16, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return CRT_OK;
+}
+
+int crt1_get_culled_visits(uint64_t* out)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!out) return CRT_E_BAD_ARGUMENT;
+    int rc = collect_timing();
+    if (rc) return rc;
+    *out = g.lastCulled;
+    return CRT_OK;
+}
+
+// Diagnostic: the range of ray origins the instance cull is proven for. limits[i] = O_i of instance i (0: never culled),
+// *sceneLimit = the smallest over the cullable instances (a frame whose camera is farther out runs without the cull),
+// *bounceReach = how far from the world origin bounce-ray origins can lie, *noCullFrames = launches that ran without it so far.
+int crt1_get_cull_range(float* limits, int n, float* sceneLimit, float* bounceReach, uint64_t* noCullFrames)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (n < 0 || n > CRT_MAX_INSTANCES || (n > 0 && !limits)) return CRT_E_BAD_ARGUMENT;
+    for (int i = 0; i < n; ++i) limits[i] = g.hCullOriginLimit[i];
+    if (sceneLimit) *sceneLimit = g.cullOriginLimit;
+    if (bounceReach) *bounceReach = g.bounceOriginReach;
+    if (noCullFrames) *noCullFrames = g.noCullFrames;
+    return CRT_OK;
+}
+
+int crt1_get_counters(CrtCounters* out)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    if (!out) return CRT_E_BAD_ARGUMENT;
+    int rc = collect_timing();
+    if (rc) return rc;
+    *out = g.lastCounters;
+    return CRT_OK;
+}
+
+} // namespace

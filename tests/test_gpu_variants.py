@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 FLAG_COUNT = 8
 
 
-@pytest.mark.parametrize("variant", ["wavefront"])
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
 def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     """The opt-in kernel structure (CRT_KERNEL=wavefront: one launch per bounce with ballot compaction in between) renders
     the same bits and counts the same work as the default megakernel. (Round 1's `persistent` and `lds` structures were
@@ -42,7 +42,8 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     assert not np.array_equal(bits(fused[0]), bits(ref)) and not np.array_equal(bits(fused[2]), bits(fused[0]))
 
 
-def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkeypatch):
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
+def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkeypatch, variant):
     """BASELINE config 4 as written ("LDS stack + wavefront compaction on"): multi-1M, 1920x1080, rendered by the wavefront form
     (crt_primary_kernel -> ballot compaction -> crt_bounce_kernel; the bounce loop of kernel_main.cl:187 split into launches)
     and compared with the ORACLE -- frame bits and every work counter -- and with the oracle-written known answer
@@ -51,7 +52,7 @@ def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkey
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_frames.json")))["multi-1M"]
     import oracle_lib
     sc = scenes.get("multi-1M")
-    monkeypatch.setenv("CRT_KERNEL", "wavefront")
+    monkeypatch.setenv("CRT_KERNEL", variant)
     with driver.Session(1920, 1080, device=0) as s:
         s.load_scene(sc)
         orc = oracle_lib.Oracle(s.arenas(), nthreads=nthreads)
@@ -68,7 +69,7 @@ def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkey
         for _ in range(5):
             s.render_raw(4)                                                # frames in flight
         assert np.array_equal(bits(s.read_output()), bits(got))
-        print(f"wavefront multi-1M 1920x1080: {st['rays']} rays, {st['secondary']} compacted bounce rays, frame and counters equal to the oracle")
+        print(f"{variant} multi-1M 1920x1080: {st['rays']} rays, {st['secondary']} compacted bounce rays, frame and counters equal to the oracle")
 
 
 def test_stamped_launch_renders_the_same_frame():

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64, 8) void chain_kernel(const float4* __restrict__
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
     uint32_t acc = 0;
     if (lane < activeLanes) {
-        uint32_t h = (wave * 64u + lane / SHARE) * 2654435761u + 12345u;
+        // SHARE == 0 (round 5): 1.5 lanes per chain -- lanes {0},{1,2},{3},{4,5},... -- the trace kernel's measured coherence (28 working lanes touch 18.45 lines)
+        uint32_t h = (wave * 64u + (SHARE == 0 ? (2u * lane + 1u) / 3u : lane / (SHARE == 0 ? 1 : SHARE))) * 2654435761u + 12345u;
         h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
         // a ray per lane: origin outside the unit cube the boxes live in, direction into it
         const float ox = -1.5f - (float)(h & 255u) * (1.0f / 256.0f), oy = 0.3f + (float)((h >> 8) & 255u) * (0.4f / 256.0f), oz = 0.3f + (float)((h >> 16) & 255u) * (0.4f / 256.0f);
@@ -373,7 +374,8 @@ int main(int argc, char** argv)
     const bool brief = argc > 1 && strcmp(argv[1], "--brief") == 0;
     const bool onlyT = argc > 1 && strcmp(argv[1], "--transposed") == 0;       // ./chain --transposed [json]: only the round-4 pairs
     const bool briefT = argc > 1 && strcmp(argv[1], "--brief-transposed") == 0;
-    FILE* js = (argc > 1 && !brief && !onlyT && !briefT) ? fopen(argv[1], "w") : (onlyT && argc > 2 ? fopen(argv[2], "w") : nullptr);
+    const bool refillRows = argc > 1 && strcmp(argv[1], "--refill") == 0;
+    FILE* js = (argc > 1 && !brief && !onlyT && !briefT && !refillRows) ? fopen(argv[1], "w") : ((onlyT || refillRows) && argc > 2 ? fopen(argv[2], "w") : nullptr);
     if (js) fprintf(js, "{\"device\": \"%s\", \"cus\": %d, \"runs\": [\n", prop.gcnArchName, numCus);
     bool firstJs = true;
     printf("%s, %d CUs; every wave 64-thread workgroup with 5 KiB LDS, launch_bounds(64, 8); hops per lane 512\n", prop.gcnArchName, numCus);
@@ -427,6 +429,15 @@ int main(int argc, char** argv)
             report("QUAD-TRANSPOSED, 64", 8, 64, run_masked<2>(dRecs, numCus * 32, 512, ~0ull, dOut, dStamps, numCus, dMismatch));
             report("per-lane fetch, 28 scattered", 8, 28, run_masked<0>(dRecs, numCus * 32, 512, 0x2A952A952A952A95ull, dOut, dStamps, numCus, dMismatch));
             report("QUAD-TRANSPOSED, 28 scattered", 8, 28, run_masked<2>(dRecs, numCus * 32, 512, 0x2A952A952A952A95ull, dOut, dStamps, numCus, dMismatch));
+            continue;
+        }
+        if (argc > 1 && strcmp(argv[1], "--refill") == 0) {
+            // round 5: what would in-tile lane refill buy the memory side? The kernel's coherence (1.5 lanes per
+            // record) at its lane count (28) and at the lane counts a refilled wave might reach, next to fully private chains
+            if (&m != &mixes[0]) break;
+            for (uint32_t lanes : { 28u, 34u, 40u, 46u, 52u, 58u, 64u }) report("4 x dwordx4, 1.5 lanes/chain", 8, lanes, run<4, 0>(dRecs, numCus * 32, 512, lanes, dOut, dStamps, numCus));
+            for (uint32_t lanes : { 28u, 40u, 52u, 64u }) report("4 x dwordx4, 1 lane/chain", 8, lanes, run<4, 1>(dRecs, numCus * 32, 512, lanes, dOut, dStamps, numCus));
+            for (uint32_t lanes : { 28u, 40u, 52u, 64u }) report("4 x dwordx4, 2 lanes/chain", 8, lanes, run<4, 2>(dRecs, numCus * 32, 512, lanes, dOut, dStamps, numCus));
             continue;
         }
         if (brief) {

@@ -54,7 +54,8 @@ if os.environ.get("CRT_KERNEL", "tile") == "persistent":
     sys.exit(0)
 lo32 = lambda a: (a & np.uint64(0xFFFFFFFF)).astype(np.float64)
 hi32 = lambda a: (a >> np.uint64(32)).astype(np.float64)
-outer, enter, desc = lo32(st[:, 4]), lo32(st[:, 5]), st[:, 6].astype(np.float64)
+outer, enter, desc = lo32(st[:, 4]), lo32(st[:, 5]), lo32(st[:, 6])
+service = hi32(st[:, 6])                    # CRT_KERNEL=refill: service steps (shade + refill) per wave
 inner2, leaf_iters = hi32(st[:, 4]), hi32(st[:, 5])
 leaf, lanev = (st[:, 7] >> np.uint64(32)).astype(np.float64), (st[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
 cyc = st[:, 2].astype(np.float64)
@@ -64,6 +65,8 @@ print("wave-level step executions: first inner step %.2fM, second inner step %.2
     desc.sum() / 1e6, inner2.sum() / 1e6, leaf.sum() / 1e6, leaf_iters.sum() / 1e6, enter.sum() / 1e6))
 print("  -> vector loads if every step took the vector path: inner 4 x %.2fM = %.2fM, leaf 3 x %.2fM = %.2fM, entries 4 x %.2fM = %.2fM (uniform entries use one scalar load instead)" % (
     (desc.sum() + inner2.sum()) / 1e6, 4 * (desc.sum() + inner2.sum()) / 1e6, leaf_iters.sum() / 1e6, 3 * leaf_iters.sum() / 1e6, enter.sum() / 1e6, 4 * enter.sum() / 1e6))
+if service.sum() > 0:
+    print("refill: service steps %.3fM (%.1f per wave), loop trips %.2fM -> %.1f trips per service step" % (service.sum() / 1e6, service.sum() / len(st), outer.sum() / 1e6, outer.sum() / service.sum()))
 print("cycles per descent trip: all waves %.0f ; slowest 1%% of waves %.0f" % (cyc.sum() / max(1.0, desc.sum()), cyc[dur >= np.percentile(dur, 99)].sum() / max(1.0, desc[dur >= np.percentile(dur, 99)].sum())))
 top = np.argsort(-dur)[:8]
 print("slowest waves: descent trips", desc[top].astype(int), "leaf trips", leaf[top].astype(int), "enter", enter[top].astype(int), "lane visits", lanev[top].astype(int))
