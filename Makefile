@@ -36,7 +36,7 @@ tools/ubench/cumask: tools/ubench/cumask.hip
 $(EXAMPLE): examples/headless_main.cpp $(HOST_SO)
 	$(CXX) $(CXXFLAGS) -o $@ examples/headless_main.cpp -Lclraytracer_amd/host -lcrt_host -Lclraytracer_amd/csrc -lcrt_hip -Wl,-rpath,'$$ORIGIN/../clraytracer_amd/host' -Wl,-rpath,'$$ORIGIN/../clraytracer_amd/csrc'
 
-$(HIP_SO): $(wildcard clraytracer_amd/csrc/*.h) clraytracer_amd/csrc/crt_shim.hip include/crt_api.h include/crt_types.h
+$(HIP_SO): $(wildcard clraytracer_amd/csrc/*.h) clraytracer_amd/csrc/crt_shim.hip include/crt_api.h include/crt_debug.h include/crt_types.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ clraytracer_amd/csrc/crt_shim.hip
 
 $(HOST_SO): $(HOST_SRC) $(HOST_HDR) $(HIP_SO)

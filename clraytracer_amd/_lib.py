@@ -55,7 +55,7 @@ _fp = C.POINTER(C.c_float)
 _vp = C.c_void_p
 _sz = C.c_size_t
 
-# name -> (restype, argtypes); kept in sync with include/crt_api.h (tests/test_abi.py checks it)
+# name -> (restype, argtypes); kept in sync with include/crt_api.h + include/crt_debug.h (tests/test_abi.py checks it)
 HIP_API = {
     "crt_init": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "crt_init_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]),

@@ -141,16 +141,14 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         } else if (count) crt_trace_refill_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters);
         else crt_trace_refill_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters);
     } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
-        const unsigned ownedPixels = (unsigned)F.ownedTileRows * CRT_TILE * (unsigned)F.width;
-        const unsigned grid2 = (ownedPixels + CRT_BLOCK - 1) / CRT_BLOCK;
-        HIPCHK(hipMemsetAsync(g.bounceCount, 0, sizeof(uint32_t), fs.stream));
-        if (count) {
-            crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<true><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
-        } else {
-            crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
-            crt_bounce_kernel<false><<<grid2, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, g.bounceQueue, g.bounceCount);
-        }
+        // per-slot state (crt1_render sized it): queue = one 64-record range per primary wave; counts, offsets, per-XCD totals
+        uint32_t* cnt = fs.wfCount; uint32_t* offs = cnt + grid; uint32_t* total = offs + grid;
+        if (count) crt_primary_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, fs.blockQueue, cnt);
+        else crt_primary_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, fs.blockQueue, cnt);
+        crt_wavefront_scan_kernel<<<8, 1024, 0, fs.stream>>>(cnt, offs, total, F.slotsPerXcd);
+        // an XCD's tiles can all continue: the bounce launch has the primary launch's shape (waves past their XCD's total leave at once)
+        if (count) crt_bounce_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, fs.blockQueue, offs, total);
+        else crt_bounce_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, fs.blockQueue, offs, total);
     } else {
         // default megakernel: <COUNT, STAMP, SHADOW, TLAS, REFRACT>
         *epilogueApplied = true;
@@ -207,7 +205,8 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
 
     // Slot choice: plain ASYNC frames of the default kernel rotate over the frame slots so consecutive frames
     // overlap (each slot has its own stream, output buffer and launch lists). Everything else -- synchronous frames,
-    // diagnostic flags, the opt-in kernel variants (they share queues / the ray buffer) -- runs on slot 0.
+    // diagnostic flags (they share the counters / the stamp and ray buffers) -- runs on slot 0. (Round 5: the wavefront form's queue belongs to
+    // the frame slot, so it keeps frames in flight like the default kernel.)
     const bool variant = g.wavefront != 0;
     if ((flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION)) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
     // CRT_KERNEL=refill: the frames the refill kernel supports (one 64-bit candidate mask, no shadow rays / refraction / instance tree / diagnostics)
@@ -215,7 +214,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
                      && args->numMeshes <= 64u && g.forceTlas != 1;
     const bool fxaa = (flags & CRT_RENDER_FXAA) != 0;
     if (fxaa && g.groupSize <= 1 && g.nRanks > 1) return CRT_E_UNSUPPORTED;                  // the filter reads across band edges
-    const bool pipelined = (flags & CRT_RENDER_ASYNC) && !variant
+    const bool pipelined = (flags & CRT_RENDER_ASYNC)
                         && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
     int slot = 0;
     if (plan) {                              // multi-device session: the dispatcher chose the slot for every device
@@ -284,9 +283,21 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
             }
         }
     }
-    {   // overflow blocks: one per workgroup of the largest launch of this frame (wavefront: the bounce launch may be larger)
+    if (variant) {                           // CRT_KERNEL=wavefront: this slot's queue (64 records per primary wave), counts + offsets + totals
+        const size_t need = (size_t)grid * 64, needCnt = (size_t)grid * 2 + 8;
+        if (need > fs.blockQueueCap || needCnt > fs.wfCap) {
+            HIPCHK(hipStreamSynchronize(fs.stream));
+            if (fs.blockQueue) (void)hipFree(fs.blockQueue);
+            if (fs.wfCount) (void)hipFree(fs.wfCount);
+            fs.blockQueue = nullptr; fs.blockQueueCap = 0; fs.wfCount = nullptr; fs.wfCap = 0;
+            HIPCHK(hipMalloc(&fs.blockQueue, need * sizeof(CrtBounceRay)));
+            fs.blockQueueCap = need;
+            HIPCHK(hipMalloc(&fs.wfCount, needCnt * sizeof(uint32_t)));
+            fs.wfCap = needCnt;
+        }
+    }
+    {   // overflow blocks: one per workgroup of the largest launch of this frame
         size_t blocks = grid;
-        if (g.wavefront) { const size_t g2 = ((size_t)F.ownedTileRows * CRT_TILE * (size_t)F.width + CRT_BLOCK - 1) / CRT_BLOCK; if (g2 > blocks) blocks = g2; }
         rc = ensure_overflow(fs, blocks); if (rc) return rc;
     }
     fill_scene(S, args->numMeshes, fs, beyond_cull_range(sqrt((double)args->cameraPos[0] * args->cameraPos[0] + (double)args->cameraPos[1] * args->cameraPos[1] + (double)args->cameraPos[2] * args->cameraPos[2])));
@@ -451,7 +462,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
 // Whether a frame with these flags rotates over the frame slots (the rule of crt1_render, for the dispatcher)
 static bool frame_is_pipelined(int flags)
 {
-    return (flags & CRT_RENDER_ASYNC) && !g.wavefront && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
+    return (flags & CRT_RENDER_ASYNC) && !(flags & (CRT_RENDER_WRITE_RAYS | CRT_RENDER_COUNTERS | CRT_RENDER_STAMPS));
 }
 
 // Diagnostic: the shader clock under whatever load the device carries right now. One wave per XCD spins for `micros`

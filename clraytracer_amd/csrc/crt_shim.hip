@@ -16,6 +16,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/crt_api.h"
+#include "../../include/crt_debug.h"
 #include "crt_kernels.h"
 #include "crt_refill.h"
 #include "crt_relayout.h"

@@ -22,7 +22,8 @@ struct FrameSlot {
     unsigned frames = 0;
     float4* out = nullptr;
     float4* aux = nullptr; size_t auxPixels = 0;   // CRT_RENDER_FXAA: the unfiltered frame the filter reads (allocated on first use)
-    CrtBounceRay* blockQueue = nullptr; size_t blockQueueCap = 0;   // CRT_KERNEL=block: the blocks' own bounce-ray queues (one range per block)
+    CrtBounceRay* blockQueue = nullptr; size_t blockQueueCap = 0;   // CRT_KERNEL=block / wavefront: bounce-ray queue, one 64- or 128-record range per workgroup of the primary launch
+    uint32_t* wfCount = nullptr; size_t wfCap = 0;                  // CRT_KERNEL=wavefront: per primary wave {continuing rays}, {offset within its XCD}, then the 8 per-XCD totals
     uint32_t* ovf = nullptr; size_t ovfBlocks = 0;   // traversal-stack overflow area of this slot's launches (CrtStack), one block per workgroup
     uint32_t* order = nullptr; uint32_t* len = nullptr; uint32_t* cost = nullptr;   // feedback launch lists
     size_t orderCap = 0; int orderSlots = -1; int orderKey[6] = { 0, 0, 0, 0, 0, 0 };
@@ -93,7 +94,7 @@ struct State {
     float lastView[35] = { 0 }; unsigned long long lastViewInst = 0; bool viewMoved = false;   // camera matrices + position / instance version of the last sorted frame
     float splitBeta = CRT_SPLIT_BETA, splitBetaAsync = CRT_SPLIT_BETA_ASYNC;   // split a tile whose wave would run longer than beta x the XCD's time for the frame
     int refill = 0;                            // CRT_KERNEL=refill / block: 1 = in-tile lane refill, 2 = phase-separated block compaction (crt_refill.h), for the frames they support
-    int wavefront = 0; CrtBounceRay* bounceQueue = nullptr; uint32_t* bounceCount = nullptr; size_t bounceCap = 0;
+    int wavefront = 0;                         // CRT_KERNEL=wavefront: one launch per bounce, ordered ballot compaction in between (crt_kernels.h)
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
     CrtBuildCtlHost* buildCtlHost = nullptr; uint32_t buildSeq = 0;   // pinned: the per-level control record the builder publishes (crt_bvh_publish)
@@ -199,23 +200,20 @@ int ensure_overflow(FrameSlot& fs, size_t blocks)
 int alloc_frame_buffers(int w, int h)
 {
     const size_t pixels = (size_t)w * (size_t)h;
-    float* rays = nullptr; CrtBounceRay* queue = nullptr; float4* outs[CRT_MAX_FRAMES_IN_FLIGHT] = {};
-    hipError_t e = hipMalloc(&queue, sizeof(CrtBounceRay) * pixels);
-    if (e == hipSuccess) e = hipMalloc(&rays, sizeof(float) * 3 * pixels);
+    float* rays = nullptr; float4* outs[CRT_MAX_FRAMES_IN_FLIGHT] = {};
+    hipError_t e = hipMalloc(&rays, sizeof(float) * 3 * pixels);
     for (int i = 0; i < g.nSlots && e == hipSuccess; ++i) {   // slots past nSlots are never rendered into
         e = hipMalloc(&outs[i], sizeof(float4) * pixels);
         if (e == hipSuccess) e = hipMemsetAsync(outs[i], 0, sizeof(float4) * pixels, g.stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
     if (e != hipSuccess) {
-        if (queue) (void)hipFree(queue);
         if (rays) (void)hipFree(rays);
         for (float4* o : outs) if (o) (void)hipFree(o);
         return (int)e;
     }
     if (g.rays) (void)hipFree(g.rays);
-    if (g.bounceQueue) (void)hipFree(g.bounceQueue);
-    g.rays = rays; g.bounceQueue = queue; g.bounceCap = pixels;
+    g.rays = rays;
     for (int i = 0; i < CRT_MAX_FRAMES_IN_FLIGHT; ++i) {
         FrameSlot& fs = g.slot[i];
         if (fs.out) (void)hipFree(fs.out);

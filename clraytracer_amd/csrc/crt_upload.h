@@ -63,7 +63,6 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMalloc(&g.counters, CRT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
-    HIPCHK(hipMalloc(&g.bounceCount, sizeof(uint32_t)));
     {   // the "never cull" bounds table of frames whose rays start beyond the cull's proven range
         static float4 never[CRT_MAX_INSTANCES];
         for (float4& b : never) b = make_float4(0.f, 0.f, 0.f, -1.0f);
@@ -106,9 +105,9 @@ static void release_all()
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
                      g.texels, g.materials, g.textures, g.rays, g.counters, g.err,
-                     g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.bounceQueue, g.bounceCount, g.noCullBounds };
+                     g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.noCullBounds };
     for (FrameSlot& fs : g.slot) {
-        void* q[] = { fs.out, fs.aux, fs.blockQueue, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
+        void* q[] = { fs.out, fs.aux, fs.blockQueue, fs.wfCount, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
         for (void* p : q) if (p) (void)hipFree(p);
         if (fs.staging) (void)hipHostFree(fs.staging);
         if (fs.staged) (void)hipEventDestroy(fs.staged);

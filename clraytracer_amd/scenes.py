@@ -408,11 +408,11 @@ def multi_1m_dense():
 
 
 # ------------------------------------------------------------------------------------------------
-# scenes made of the reference's own shipped assets (tests/golden/assets: .clm mesh caches + JPEG textures, data files
+# scenes made of the reference's own shipped assets (assets/: .clm mesh caches + JPEG textures, data files
 # copied from upstream's CLRayTracer/Assets). Loaded exactly as upstream would: ImportMesh("Assets/x/x.obj") finds the
 # .clm cache (AssetManager.cpp:363-381), whose MTL text names the JPEG textures (ResourceManager.cpp:262-266).
 # ------------------------------------------------------------------------------------------------
-ASSET_ROOT = os.path.join(_lib.ROOT, "tests", "golden", "assets")
+ASSET_ROOT = os.path.join(_lib.ROOT, "assets")
 
 
 def _asset(rel):

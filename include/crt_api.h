@@ -196,27 +196,6 @@ int crt_get_culled_visits(uint64_t* out);
  * cull (same results, every instance entered as upstream does, kernel_main.cl:198); *bounceReach = how far out bounce-ray origins
  * can lie (object-space hit points, hazard H6); *noCullFrames = launches that ran without the cull so far. Any pointer may be NULL. */
 int crt_get_cull_range(float* limits, int n, float* sceneLimit, float* bounceReach, uint64_t* noCullFrames);
-/* Diagnostic: per wave of the last CRT_RENDER_STAMPS launch, 8 x uint64 {start, end (s_memrealtime, 100 MHz),
- * shader cycles, XCC_ID | HW_ID << 32, wave-level trips of the outer loop | second-inner-step executions << 32,
- * enter-instance steps | wave-level triangle iterations << 32, first-inner-step executions, leaf steps << 32 | lane-level node
- * visits}. Pass dst = NULL to query the wave count. */
-int crt_debug_read_stamps(uint64_t* dst, size_t maxWaves, size_t* numWaves);
-/* Diagnostic: {start, end} in ms after the start of the first frame, for each of the (up to 256) frames timed since the last
- * crt_frame_time_stats(..., reset = 1), in the order their timing was collected: how a burst of frames in flight fills and drains. */
-int crt_debug_read_frame_times(double* dst, size_t maxFrames, size_t* numFrames);
-/* Diagnostic: the shader clock (GHz) the device holds under whatever load it carries while the call runs: one wave per XCD
- * watches s_memtime against the 100 MHz s_memrealtime for `micros` microseconds on a stream of its own (bench.py calls it
- * beside frames in flight so that cycle-based figures use the measured clock, not the 2.4 GHz nominal one). */
-int crt_debug_measure_clock(int micros, double* ghz);
-/* Test hook (multi-device sessions): the next crt_render / crt_resize fails on session device `device` as if that
- * device's submission had returned an error, once. Exercises the "a secondary failed" paths of the dispatcher. Refused with
- * CRT_E_UNSUPPORTED unless the process runs with CRT_DEBUG_HOOKS=1 in its environment. */
-int crt_debug_inject_failure(int device);
-/* Diagnostic: frames of this session that were held back by the start-up stagger of a burst of CRT_RENDER_ASYNC frames (a
- * caller that streams -- the burst before ran longer than the frame-slot count -- has the first frame of slots 1.. of a new burst
- * delayed by slot x latency / slots so that the slots do not run in lockstep; CRT_STAGGER_US=0 turns it off, =n forces n us). */
-int crt_debug_staggered_frames(uint64_t* out);
-
 const char* crt_error_string(int code);
 const char* crt_device_name(void);
 

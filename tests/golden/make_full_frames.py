@@ -3,7 +3,7 @@
 pre-PostProcess float frame, of the shadow-extension frame and of the RGBA8 (hazard H8) bytes, plus the work counters,
 for the synthetic scenes and the two scenes made of the reference's shipped assets -> tests/golden/full_frames.json. Run from the repo root (about a minute on 8 cores):
     python tests/golden/make_full_frames.py
-The scenes are generated from seeds (clraytracer_amd/scenes.py) or loaded from tests/golden/assets, so the fixture is
+The scenes are generated from seeds (clraytracer_amd/scenes.py) or loaded from assets/, so the fixture is
 machine-independent."""
 import hashlib
 import json

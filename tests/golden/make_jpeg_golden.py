@@ -5,7 +5,7 @@ oracle/_ref/libstb_image_ref.so (oracle/Makefile `ref`), exactly as ResourceMana
 stbi_load(path, &w, &h, &channels, 3) -- and the SHA-256 of the RGB8 bytes is recorded in tests/golden/jpeg_stb.json.
 Runs only where /root/reference is mounted (the build container):
     python tests/golden/make_jpeg_golden.py
-The subset of those files that the asset scenes need is committed under tests/golden/assets/Assets (data fixtures), so
+The subset of those files that the asset scenes need is committed under assets/Assets (data fixtures), so
 tests/test_jpeg.py can check the product's decoder against these hashes anywhere."""
 import ctypes as C
 import glob

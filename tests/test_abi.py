@@ -17,8 +17,10 @@ def declared(header, prefix):
 
 
 def test_hip_library_exports_every_declared_symbol():
-    names = declared("crt_api.h", "crt_")
-    assert len(names) >= 24
+    api, dbg = declared("crt_api.h", "crt_"), declared("crt_debug.h", "crt_")
+    assert len(api) >= 24 and not [n for n in api if n.startswith("crt_debug_")]      # the drop-in surface holds no diagnostics
+    assert dbg and all(n.startswith("crt_debug_") for n in dbg)
+    names = sorted(api + dbg)
     lib = C.CDLL(_lib.HIP_SO)
     for n in names:
         assert hasattr(lib, n), n

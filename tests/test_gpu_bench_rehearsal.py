@@ -80,17 +80,33 @@ def test_single_gpu_line_carries_the_contract_and_the_round_3_objects():
     # the contract's HBM roofline: achieved = PMC traffic / this run's device time, never above the peak; everything else beside it
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and "frac_definition" in r and r["error"] is None
     assert r["traffic"] is None or (r["traffic"] > 0 and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] == r["hbm_frac"])
-    import shutil
-    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):      # the run measured its own HBM traffic: within 10 % of the committed passes
+    # the run re-measures its own HBM traffic at its end (two rocprofv3 --pmc child runs, 60 s budget): when that worked the figure is within
+    # 10 % of the committed passes; when it did not (no rocprofv3, --pmc not permitted on this box, budget spent) the committed figure stands and
+    # the line says so -- either way the line is whole (tests/test_gpu_bench_rehearsal.py::test_line_is_whole_without_the_profiler forces the latter)
+    assert isinstance(r["traffic_live_ok"], bool) and isinstance(r["traffic_live_child_rc"], list)
+    if r["traffic_live_ok"]:
         assert r["traffic_source"].startswith("live"), r["traffic_live_note"]
         assert r["traffic_committed_profile"] is None or abs(r["traffic"] - r["traffic_committed_profile"]) <= 0.1 * r["traffic_committed_profile"]
+    else:
+        assert r["traffic_live_note"] and (r["traffic"] is None or r["traffic"] == r["traffic_committed_profile"])
     assert r["algorithmic_over_hbm_peak"] > 1.0                             # a work measure, flagged as such in frac_definition
     assert r["l2"] is None or (0 < r["l2"]["frac"] < 1.0 and r["l2"]["peak"] == 34500.0 and 0 < r["l1_hit"] < 1 and 0 < r["l2_hit"] < 1 and r["lds_instructions_per_launch"] > 0)
     assert r["chain"] is not None and r["chain"]["kind"].startswith("model") and r["chain"]["ceiling"] > 0 and 0.5 < r["chain"]["clock_ghz"] < 2.6
     assert r["vmem_pipe"] is None or 0 < r["vmem_pipe"]["busy_modelled"] < 1.5
     assert "stagger" in d["config"] and "3840x2160" in d["config"]["n_gt_1_lines"]
-    for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "scale_base_n1", "wavefront_compaction"):
+    for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "config3", "config2", "scale_base_n1",
+                "wavefront_compaction", "in_wave_refill", "in_wave_block_compaction"):
         assert d[key]["value"] > 0 and d[key]["rays_per_frame"] > 0, key
+    # every BASELINE config has its rocprof HBM figure: traffic from a committed profile of exactly that workload
+    for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "config3", "config2", "scale_base_n1"):
+        h = d[key]["hbm"]
+        assert h is not None and h["traffic"] > 0 and 0 < h["frac"] <= 1.0 and h["traffic_source"].startswith("profiles/r05") and 0 < h["l1_hit"] < 1 and 0 < h["l2_hit"] < 1, key
+    # compaction three ways, each against the default kernel in the same mode
+    for key in ("wavefront_compaction", "in_wave_refill", "in_wave_block_compaction"):
+        assert d[key]["vs_default_kernel_in_flight"] > 0 and d[key]["vs_default_synchronous"] > 0 and d[key]["rays_per_frame"] == d["config"]["rays_per_frame"], key
+    # SURVEY 8f rank 1's other half in the driver's record
+    assert d["many_instances"]["instances"] == 401 and d["many_instances"]["value"] > 0 and d["many_instances"]["tlas_vs_linear"] > 1.0
+    assert d["animated_instances"]["value"] > 0 and 0.3 < d["animated_instances"]["vs_static"] <= 1.1
     assert 0 < d["bvh_build"]["ms"] < 100 and d["bvh_build"]["nodes"] > d["bvh_build"]["triangles"] and 0 < d["bvh_build"]["frac_of_hbm"] < 1
     assert d["wavefront_compaction"]["synchronous_frames"] > 0 and d["wavefront_compaction"]["rays_per_frame"] == d["config"]["rays_per_frame"]
     assert d["with_shadow_rays"]["shadow_rays_per_frame"] > 0 and d["dense_view"]["primary_hit_fraction"] > 0.9
@@ -98,3 +114,15 @@ def test_single_gpu_line_carries_the_contract_and_the_round_3_objects():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["primary_hits_consistent"] and c["trace_oracle"]["rays_match_gpu"]
     assert c["config1_cornell_1k_640x480"]["value"] > 0 and c["config1_cornell_1k_640x480"]["primary_hits"] > 0
+
+
+def test_line_is_whole_without_the_profiler(tmp_path):
+    """The live PMC passes are a measurement aid: with no rocprofv3 on PATH the N = 1 line must still come out whole, its `traffic` from the
+    committed profile, and say what happened (VERDICT r4 #4d)."""
+    clean = os.pathsep.join(p for p in os.environ.get("PATH", "").split(os.pathsep) if p and not os.path.exists(os.path.join(p, "rocprofv3")))
+    d = run_bench([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--prewarm-ms", "10", "--no-extras", "--live-pmc"],
+                  {"CRT_BENCH_REHEARSE": "0", "PATH": clean})
+    r = d["roofline"]
+    assert r["traffic_live_ok"] is False and "rocprofv3 not found" in r["traffic_live_note"] and r["traffic_live_child_rc"] == []
+    assert r["traffic"] == r["traffic_committed_profile"] and r["traffic_source"].startswith("profiles/") and 0 < r["frac"] <= 1.0 and r["error"] is None
+    assert d["value"] > 0 and d["synchronous_frames"]["value"] > 0

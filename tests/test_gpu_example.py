@@ -39,7 +39,7 @@ def test_cpp_example_renders_upstream_sponza_on_two_device_states(tmp_path):
     """The same program on upstream's own Sponza cache with its JPEG textures (CRT_ASSET_ROOT) and on two device states
     (CRT_DEVICES=0,0: Renderer::InitializeDevices): identical to the Python driver's single-device frame."""
     exe = os.path.join(ROOT, "examples", "crt_headless")
-    assets = os.path.join(ROOT, "tests", "golden", "assets")
+    assets = os.path.join(ROOT, "assets")
     w, h = 480, 272
     out = str(tmp_path / "sponza.ppm")
     pos, front = (-3.0, 19.5, 3.5), scenes._normalize((0.25, -1.0, -0.55))

@@ -4,7 +4,7 @@ stb_image v2.27). The product's own decoder (clraytracer_amd/host/JpegDecode.cpp
 What pins what:
 * tests/golden/jpeg_stb.json holds, for every JPEG the reference ships, the SHA-256 of the bytes the REFERENCE's decoder
   produces (tests/golden/make_jpeg_golden.py runs the reference's stb_image.h, compiled as it lies into oracle/_ref/).
-* The JPEGs the asset scenes use are committed under tests/golden/assets (data) -> checked everywhere, CPU only.
+* The JPEGs the asset scenes use are committed under assets/ at the repository root (data) -> checked everywhere, CPU only.
 * Where /root/reference is mounted, all 47 shipped JPEGs are checked, and where oracle/_ref/libstb_image_ref.so exists the
   two decoders are also compared live, byte for byte, including on damaged streams (same pixels whenever both decode).
 Coverage of the shipped set: baseline and progressive, 4:4:4 and 4:2:0, grey-scale, restart intervals, Adobe APP14,
@@ -21,7 +21,7 @@ from clraytracer_amd import _lib, driver
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "jpeg_stb.json")))
-FIXTURES = os.path.join(HERE, "golden", "assets", "Assets")
+FIXTURES = os.path.join(os.path.dirname(HERE), "assets", "Assets")
 REF_ASSETS = "/root/reference/CLRayTracer/Assets"
 REF_SO = os.path.join(_lib.ROOT, "oracle", "_ref", "libstb_image_ref.so")
 
@@ -142,7 +142,7 @@ def test_rejects_non_jpeg_and_unsupported():
 def test_import_texture_reads_jpeg_with_windows_path_semantics(tmp_path):
     """ResourceManager::ImportTexture on a JPEG: texel arena bytes == decoder output; the path is found under the asset
     root although the MTL spells it with a different case (upstream's sponza.mtl says 01_ST_KP.JPG, the file is 01_St_kp.JPG)."""
-    root = os.path.join(HERE, "golden", "assets")
+    root = os.path.join(os.path.dirname(HERE), "assets")
     g = GOLD["sponza/01_St_kp.JPG"]
     with driver.Session(64, 48, host_only=True) as s:
         h = s.h
@@ -160,7 +160,7 @@ def test_import_texture_reads_jpeg_with_windows_path_semantics(tmp_path):
 def test_asset_scene_imports_every_texture_upstream_would():
     """sponza.clm through ImportMesh: 20 materials, one ImportTexture per map_Kd (19, duplicates included, as upstream:
     ResourceManager.cpp:262-266 does not de-duplicate) -> texture indices 2..20 after the two defaults."""
-    root = os.path.join(HERE, "golden", "assets")
+    root = os.path.join(os.path.dirname(HERE), "assets")
     with driver.Session(64, 48, host_only=True) as s:
         h = s.h
         h.crth_set_asset_root(root.encode())

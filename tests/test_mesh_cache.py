@@ -12,7 +12,7 @@ from clraytracer_amd import _lib, driver, scenes
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libquicklz_ref.so")
-REF_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets", "Assets")   # the caches upstream ships, committed as data fixtures
+REF_ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "Assets")   # the caches upstream ships, committed as data fixtures
 
 
 def qlz_decompress(data, out_len):
@@ -138,7 +138,7 @@ def test_cache_written_on_import_and_preferred_afterwards(level, tmp_path):
 
 
 FIXTURE_CLMS = ["sponza/sponza.clm", "sibenik/sibenik.clm", "nanosuit/nanosuit.clm"]
-FIXTURE_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets", "Assets")
+FIXTURE_ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "Assets")
 
 
 def _clm_stream(blob):
