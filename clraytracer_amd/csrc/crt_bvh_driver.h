@@ -25,7 +25,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     // second triangle pool (allocated on first use, indexed like rawTris) and scratch:
     // build nodes | rank, holes, backL | 2 x 3 id lists | 2 x BIG-node scratch | 2 x chunk->node + 3 per-chunk counts | mesh counts, roots | scalars
     if (!g.buildTris) HIPCHK(hipMalloc(&g.buildTris, g.triCap * sizeof(CrtTri)));
-    if (!g.buildCtlHost) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g.buildCtlHost), sizeof(CrtBuildCtlHost), hipHostMallocDefault)); g.buildCtlHost->seq = 0; g.buildSeq = 0; }
+    if (!g.buildCtlHost) { HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&g.buildCtlHost), sizeof(CrtBuildCtlHost), hipHostMallocMapped | hipHostMallocCoherent)); g.buildCtlHost->seq = 0; g.buildSeq = 0; }
     const size_t maxNodes = 2 * total + (size_t)numMeshes;
     const size_t offNodes = 0;
     const size_t offRank = (offNodes + maxNodes * sizeof(CrtBuildNode) + 255) & ~(size_t)255;
@@ -119,12 +119,17 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
             crt_bvh_publish<<<1, 1, 0, st>>>(dCtl, g.buildCtlHost, seq);
             HIPCHK(hipGetLastError());
             bool arrived = false;
-            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+            for (unsigned spin = 0; spin < (1u << 22) && !g.buildNoSpin; ++spin) {
                 if (g.buildCtlHost->seq == seq) { arrived = true; break; }
                 if ((spin & 0x3FFu) == 0x3FFu && hipStreamQuery(st) != hipErrorNotReady) break;      // finished (or failed) without our flag: let the sync below sort it out
-                __builtin_ia32_pause();
+                crt_cpu_relax();
             }
-            if (!arrived) { HIPCHK(hipStreamSynchronize(st)); if (g.buildCtlHost->seq != seq) return CRT_E_UNSUPPORTED; }
+            if (!arrived) {
+                // the record did not become visible while the level ran (host memory that is not coherent with running kernels): from now on
+                // wait for the stream at once instead of burning the spin budget on every level
+                HIPCHK(hipStreamSynchronize(st)); if (g.buildCtlHost->seq != seq) return CRT_E_UNSUPPORTED;
+                if (!g.buildNoSpin) { g.buildNoSpin = true; fprintf(stderr, "[crt] crt_build_bvh: the pinned control record is not visible before the stream drains; using stream synchronisation per level\n"); }
+            }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             ctl = g.buildCtlHost->ctl;
         }

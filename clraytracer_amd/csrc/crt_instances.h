@@ -87,7 +87,9 @@ void rebuild_instance_master()
             if (far > reach || !(far == far)) reach = far;
         }
     }
-    g.bounceOriginReach = (float)reach;
+    // ... and no farther than the farthest uploaded vertex: trees that arrive through crt_upload_bvh_nodes need not bound their triangles
+    { const double far = sqrt(g.triReach2) * (1.0 + 1e-5) + 0.02; if (far > reach || !(far == far)) reach = far; }
+    g.bounceOriginReach = reach < 3.0e38 ? (float)reach : 3.0e38f;
     double minLimit = 1e30;
     // test hook (CRT_DEBUG_HOOKS=1 only): CRT_DEBUG_CULL_RANGE_SCALE=k multiplies every O_i -- tools/fuzz_cull.py uses it to measure how far
     // beyond the proven range the cull stays exact in practice (the derivation is a worst-case bound)

@@ -35,7 +35,7 @@ struct Worker {
             for (;;) {
                 int spins = 0;
                 while (posted.load(std::memory_order_acquire) == seen && !quit.load(std::memory_order_acquire)) {
-                    if (++spins < kSpins) { __builtin_ia32_pause(); continue; }
+                    if (++spins < kSpins) { crt_cpu_relax(); continue; }
                     std::unique_lock<std::mutex> lk(m);
                     cv.wait(lk, [&] { return posted.load(std::memory_order_acquire) != seen || quit.load(std::memory_order_acquire); });
                 }
@@ -59,7 +59,7 @@ struct Worker {
         const unsigned want = posted.load(std::memory_order_acquire);
         int spins = 0;
         while (finished.load(std::memory_order_acquire) != want) {
-            if (++spins < kSpins) { __builtin_ia32_pause(); continue; }
+            if (++spins < kSpins) { crt_cpu_relax(); continue; }
             std::unique_lock<std::mutex> lk(m);
             cv.wait(lk, [&] { return finished.load(std::memory_order_acquire) == want; });
         }

@@ -79,6 +79,7 @@ struct State {
     // Range of ray origins for which the instance cull is provably exact (derivation: crt_device.h above sphere_culls):
     // per instance and the smallest over the cullable ones; a frame / query whose origins lie beyond it runs with `noCullBounds`.
     float hCullOriginLimit[CRT_MAX_INSTANCES]; float cullOriginLimit = 0.0f; float bounceOriginReach = 0.0f;
+    double triReach2 = 0.0;                    // largest squared distance of an uploaded vertex from its object-space origin (crt1_upload_triangles)
     float4* noCullBounds = nullptr;            // device: CRT_MAX_INSTANCES x (0, 0, 0, -1) = "never cull"
     unsigned long long noCullFrames = 0;       // frames and queries that ran without the cull for that reason
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;
@@ -97,6 +98,7 @@ struct State {
     int wavefront = 0;                         // CRT_KERNEL=wavefront: one launch per bounce, ordered ballot compaction in between (crt_kernels.h)
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
+    bool buildNoSpin = false;                                   // the spin on buildCtlHost timed out once: synchronise the stream per level instead
     CrtBuildCtlHost* buildCtlHost = nullptr; uint32_t buildSeq = 0;   // pinned: the per-level control record the builder publishes (crt_bvh_publish)
     CrtTri* buildTris = nullptr;                               // crt_build_bvh: second triangle pool (same indexing as rawTris)
     size_t triCap = 0, nodeCap = 0, texelByteCap = 0;
@@ -115,6 +117,16 @@ struct State {
 // calling thread or on a per-device worker thread.
 thread_local State* G = nullptr;
 #define g (*G)
+
+// a spinning host thread's pause (the level read-back of crt_build_bvh, the per-device workers): x86 `pause`, otherwise a compiler barrier
+static inline void crt_cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
 
 #define CRT_NUM_COUNTERS 15
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return (int)e_; } } while (0)

@@ -166,6 +166,20 @@ int crt1_upload_triangles(const void* tris, size_t byteOffset, size_t bytes)
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
     if (first + count > g.trisHigh) g.trisHigh = first + count;
+    {   // how far from the object-space origin a vertex (hence a hit point, hence a bounce-ray origin, hazard H6) can lie: the cull's
+        // proven range is checked against this as well as against the root boxes, so that nodes uploaded through crt_upload_bvh_nodes
+        // whose boxes do not bound their triangles cannot take bounce origins beyond it. Monotonic until the next crt_init.
+        const float* v = static_cast<const float*>(tris);
+        double far2 = g.triReach2;
+        bool bad = false;
+        for (size_t t = 0; t < count; ++t, v += sizeof(CrtTri) / sizeof(float))
+            for (int k = 0; k < 3; ++k) {
+                const double x = v[4 * k], y = v[4 * k + 1], z = v[4 * k + 2], d2 = x * x + y * y + z * z;
+                if (!(d2 == d2)) bad = true; else if (d2 > far2) far2 = d2;
+            }
+        if (bad) far2 = 1e300;
+        if (far2 > g.triReach2) { g.triReach2 = far2; rebuild_instance_master(); }
+    }
     return CRT_OK;
 }
 

@@ -335,10 +335,14 @@ void ResourceManager::PushMeshesToGPU() // ResourceManager.cpp:280-300
         int rc = crt_upload_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
         int built = rc;
         if (rc == 0) built = crt_build_bvh(lastTriangleCount, counts, newMeshes, lastBVHIndex, numberOfBVH, &numNodesUsed);
-        if (rc == 0 && built != 0) {
-            // the device builder refused (a size beyond its scratch layout, or its consistency checks): the host arenas still hold the
+        if (rc == 0 && (built == CRT_E_OUT_OF_RANGE || built == CRT_E_UNSUPPORTED)) {
+            // the device builder REFUSED (a size beyond its scratch layout, or its consistency checks): the host arenas still hold the
             // triangles as imported, so the host BuildBVH below takes over and its uploads replace whatever the device build left behind
-            std::fprintf(stderr, "[ResourceManager] crt_build_bvh failed (%d): building on the host\n", built);
+            std::fprintf(stderr, "[ResourceManager] crt_build_bvh refused (%d): building on the host\n", built);
+        } else if (rc == 0 && built != 0) {
+            // anything else (a HIP error: a faulting kernel, a failed stream synchronisation) is reported where it happened, not papered over
+            note(built, "crt_build_bvh");
+            return;
         } else {
             if (rc == 0) rc = crt_download_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
             if (rc == 0) rc = crt_download_bvh_nodes(g_BVHNodes + lastBVHIndex, lastBVHIndex * sizeof(BVHNode), sizeof(BVHNode) * numNodesUsed);

@@ -110,7 +110,10 @@ int crt_band_plan(int height, int bandRows, int rank, int nRanks, int out[4]);
 
 /* ResourceManager.cpp:286 -- triangles in the 80-byte reference layout, offsets in bytes. */
 int crt_upload_triangles(const void* tris, size_t byteOffset, size_t bytes);
-/* ResourceManager.cpp:293 -- BVH nodes (32 B each), offsets in bytes, indices as built on the host. */
+/* ResourceManager.cpp:293 -- BVH nodes (32 B each), offsets in bytes, indices as built on the host.
+ * Trees from BuildBVH / crt_build_bvh bound their triangles; uploaded nodes need not (leaf triangles are tested without a box test,
+ * kernel_main.cl:135-140). The instance cull stays exact either way: the range of bounce-ray origins it is proven for is taken from the
+ * uploaded triangles' extents as well as from the root boxes (crt_get_cull_range: bounceReach). */
 int crt_upload_bvh_nodes(const void* nodes, size_t byteOffset, size_t bytes);
 /* ResourceManager.cpp:291 -- per-mesh root node indices (uint32). */
 int crt_upload_bvh_roots(const uint32_t* roots, size_t firstMesh, size_t count);

@@ -10,7 +10,7 @@ want=$(sha256sum < "$saved")
 restore() {
   cp "$saved" clraytracer_amd/csrc/libcrt_hip.so
   [ "$(sha256sum < clraytracer_amd/csrc/libcrt_hip.so)" = "$want" ] || echo "WARNING: the restored libcrt_hip.so is not the library this run started with -- rebuild with make" >&2
-  rm -f "$saved" "$variant"
+  rm -f "$saved"
 }
 trap restore EXIT
 names="$@"; [ -z "$names" ] && names=$(ls build/ab)

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Experiment (GPU box, library built with -DCRT_EXP_TOPCOUNT, see tools/ab_build.sh): how many of the trace kernel's vector-path
+"""Round-3 experiment, kept for the record: -DCRT_EXP_TOPCOUNT no longer exists in the tree (tools/experiments/r03_ab_arms.patch brings the
+counting arm back against round 3's crt_device.h); results: profiles/r03_top_count.txt.
+Experiment (GPU box, library built with -DCRT_EXP_TOPCOUNT, see tools/ab_build.sh): how many of the trace kernel's vector-path
 inner-node fetches go to the top K levels of a mesh's tree? The node array is renumbered so that every mesh's top-K child pairs come
 first (tools/top_layout.py; same tree, same frame) and the counting instantiation reports, per frame: lane-level vector-path fetches,
 those to a top record, and those in a wave-level step where EVERY active lane wanted a top record (the steps an LDS-resident copy of
 the top records would take off the vector-memory path altogether).
     CRT_EXP_TOP_PAIRS=<T> is set per K by this script before the session starts (one process per K)."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 2 and sys.argv[1] == "--one":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
     import numpy as np
