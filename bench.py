@@ -134,6 +134,7 @@ def main():
     dist = None
     ctl = None              # process group for barriers/reductions (None = the default gloo group)
     control_plane = None
+    rccl_seen = None        # what the RCCL probe's all-reduce of 1 over the ranks returned on this rank (= the number of ranks RCCL really connected)
     if n > 1 or os.environ.get("CRT_BENCH_FORCE_DIST") == "1":   # FORCE_DIST: exercise the RCCL control plane with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -154,7 +155,8 @@ def main():
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe, group=ctl)
                 torch.cuda.synchronize()
-                ok = int(probe.item() == world)
+                rccl_seen = int(probe.item())
+                ok = int(rccl_seen == world)
             except Exception as e:  # pragma: no cover - depends on the node
                 sys.stderr.write(f"[bench] rank {rank}: RCCL group unavailable ({e})\n")
                 ok = 0
@@ -499,6 +501,7 @@ def main():
         if warnings:
             out["warnings"] = warnings
         if n > 1:
+            out["config"]["rccl_ranks_seen"] = rccl_seen      # N ranks behind one RCCL communicator (None: gloo control plane / one process)
             out["config"]["gather_path"] = hip.crt_gather_path().decode() if inproc else "none: every rank keeps its bands (delivered_to_host* copy them to pinned host memory)"
             if inproc:
                 out["config"]["peer_access"] = [int(hip.crt_peer_access(d)) for d in range(n)]

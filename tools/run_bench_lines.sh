@@ -8,6 +8,7 @@ for sc in multi-1M-dense sponza-sibenik nanosuit-demo sponza-class-250k cornell-
   python bench.py --scene $sc --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
 done
 python bench.py --shadows --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
+python bench.py --scene sponza-class-250k --shadows --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err   # BASELINE config 3 as written
 python bench.py --width 3840 --height 2160 --no-cpu-baseline >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
 python bench.py --frames-in-flight 1 --no-cpu-baseline --no-extras >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras >> $out/${tag}_bench_lines.jsonl 2>>$out/${tag}_bench.err   # the driver's step counts
