@@ -15,7 +15,7 @@
 // instruction. Shading (kernel_main.cl:219-272) moves INTO the traversal loop as a "service step": lanes whose ray is finished
 // wait until CRT_REFILL_BATCH of them have gathered (or until they outnumber half the lanes still traversing), then shade
 // together, start their bounce ray or store their pixel and draw the next one. The pixel index (and the bounce number in bit 31)
-// waits in a parked LDS slot (CrtStackT<1>), so the kernel carries no more registers across the traversal than the megakernel does.
+// and the path's energy wait in parked LDS slots (CrtStackT<2>), so the kernel carries no more registers across the traversal than the megakernel does.
 //
 // Limits: up to 64 instances (one candidate mask), no shadow rays / refraction / instance tree: those frames take the megakernel.
 #pragma once
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(CRT_BLOCK, (COUNT || STAMP) ? CRT_WAVES_PER_SIMD_CO
 void crt_trace_refill_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out, unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_stack[CRT_LDS_SLOTS * CRT_BLOCK];
-    typedef CrtStackT<1> Stack;                              // parked slot 0: pixel index within the block | bounce << 31
+    typedef CrtStackT<2> Stack;                              // parked slots: [0] pixel index within the block | bounce << 31, [1] the path's energy
     const Stack stack = { (crt_lds_u32_ptr)s_stack + threadIdx.x, S.stackOverflow };
     LaneCounters lc; zero_counters(lc);
     unsigned long long t0rt = 0, t0c = 0;
@@ -110,12 +110,14 @@ void crt_trace_refill_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out
                     T.reset();                                // (the traversal is idle: nothing of it needs to survive the shading code)
                     const uint32_t st = stack.parked(0);
                     const int bounce = (int)(st >> 31);
+                    ps.energy = __uint_as_float(stack.parked(1));      // (waits in LDS through the traversals, as in the megakernel's SHADOW instantiations)
                     const int cont = shade_bounce(S, c, ps, bounce, F.lightY, F.lightZ);
                     c.distance = 99999.0f; c.hitInstance = 0; c.anyHit = 0;
                     c.hit.t = 0.0f; c.hit.u = 0.0f; c.hit.v = 0.0f; c.hit.tri = 0;
                     if (COUNT) { if (cont) lc.hits++; else lc.misses++; }
                     if (cont != 0 && bounce == 0) {           // kernel_main.cl:187: the second iteration of the bounce loop
                         stack.park(0, st | 0x80000000u);
+                        stack.park(1, __float_as_uint(ps.energy));
                         newRay = true;
                         if (COUNT) { lc.rays++; lc.secondary++; }
                     } else {
@@ -144,7 +146,7 @@ void crt_trace_refill_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out
                             asm volatile("" : "+s"(w2), "+s"(h2));
                             ps.d = raygen_dir(F, px, py, w2, h2);
                             ps.result = mk3(0.0f, 0.0f, 0.0f);
-                            ps.energy = 1.0f;
+                            stack.park(1, __float_as_uint(1.0f));
                             newRay = true;
                             if (COUNT) { lc.rays++; lc.primary++; }
                         }
@@ -206,7 +208,7 @@ void crt_trace_refill_kernel(CrtDevScene S, CrtFrame F, float4* __restrict__ out
 // ------------------------------------------------------------------------------------------------------------------------------
 // crt_trace_block_kernel (CRT_KERNEL=block) -- PHASE-SEPARATED compaction inside the wave.
 //
-// What the refill form above taught (profiles/r05_refill.md): a wave that mixes rays at different stages executes every step kind
+// What the refill form above taught (profiles/r05_in_wave_compaction_timeline.txt, r05refill_summary.md): a wave that mixes rays at different stages executes every step kind
 // (enter / inner / leaf) on every trip, so the wave-level instruction count falls far less than the lane utilisation rises, and
 // the service steps cost what the packing saves. Here the rays of a block are regrouped BETWEEN the stages instead, so every
 // traversal still runs as a packet of rays that start together:

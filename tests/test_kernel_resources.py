@@ -39,3 +39,10 @@ def test_plain_trace_instantiations_need_no_scratch_and_64_vgprs():
     # the instrumented instantiations may use more registers (6 waves/SIMD); the default counted and stamped ones must not spill either
     assert rows["crt_trace_kernel<true, false, false, false, false>"]["ScratchSize"] == 0
     assert rows["crt_trace_kernel<false, true, false, false, false>"]["ScratchSize"] == 0          # the stamped diagnostic launch
+    # round 5: the refill kernel met the gate it was given (64 VGPRs, no scratch, occupancy 8) -- its loss is not a register artefact;
+    # the wavefront form's two kernels run at the default kernel's occupancy too
+    r = rows["crt_trace_refill_kernel<false, false>"]
+    assert r["ScratchSize"] == 0 and r["VGPRs"] <= 64 and r["Occupancy"] == 8 and r["LDS Size"] == 5120, r
+    for name in ("crt_primary_kernel<false>", "crt_bounce_kernel<false>"):
+        assert rows[name]["ScratchSize"] == 0 and rows[name]["VGPRs"] <= 64 and rows[name]["Occupancy"] == 8, (name, rows[name])
+    assert rows["crt_trace_block_kernel<false, false>"]["VGPRs"] <= 64 and rows["crt_trace_block_kernel<false, false>"]["Occupancy"] == 8
