@@ -557,12 +557,10 @@ __global__ void crt_bvh_big_degenerate_mark(CrtBuildNode* __restrict__ nodes, co
 #define CRT_BVH_WAVES 8
 #define CRT_BVH_LDS_TABLE 128         // partition tables of nodes up to this size live in LDS, larger ones in the global scratch
 // UpdateNodeBounds (BVH.cpp:54-74) for the nodes list[0 .. count): min/max reductions per wave.
-__global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_bounds_wave(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, const CrtTri* __restrict__ tris)
+// (round 5: called at the top of crt_bvh_mid -- the wave reads its node's triangles for the bins anyway; as a kernel of its own it was 12
+// launches of a 1 M-triangle build. All 64 lanes of the node's wave must call.)
+__device__ __forceinline__ void bvh_bounds_wave_body(CrtBuildNode& node, const uint32_t first, const uint32_t n, const uint32_t lane, const CrtTri* __restrict__ tris)
 {
-    const uint32_t k = blockIdx.x * CRT_BVH_WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k >= count) return;                                   // whole waves leave; no workgroup barrier below
-    CrtBuildNode& node = nodes[list[k]];
-    const uint32_t first = node.first, n = node.count;
     float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
     for (uint32_t i = lane; i < n; i += 64) {
         const float* t = bvh_tri_f(tris, (size_t)first + i);
@@ -603,7 +601,7 @@ __global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_bounds_wave(CrtBui
         for (int c = 0; c < 3; ++c) { node.bmin[c] = rmin[c]; node.bmax[c] = rmax[c]; }
 }
 
-// FindBestSplitPlane + the split decision + the partition (BVH.cpp:103-163, 165-216) for the nodes list[0 .. count).
+// UpdateNodeBounds + FindBestSplitPlane + the split decision + the partition (BVH.cpp:54-74, 103-163, 165-216) for the nodes list[0 .. count).
 __global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_mid(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count,
                                                                   CrtTri* __restrict__ src, CrtTri* __restrict__ dst, uint32_t poolFirst,
                                                                   uint32_t* __restrict__ rank, uint32_t* __restrict__ holes, uint32_t* __restrict__ backL,
@@ -621,6 +619,7 @@ __global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_mid(CrtBuildNode* 
     const uint32_t first = node.first, n = node.count;
     unsigned long long inc = 0; uint32_t L = 0;
     if (live) {
+        bvh_bounds_wave_body(node, first, n, lane, src);       // lane 0 stores the bounds; the wave syncs below come before anybody reads them
         for (int j = lane; j < 3 * CRT_BVH_BINS; j += 64) (&s_cnt[w][0][0])[j] = 0;
         for (int j = lane; j < 9 * CRT_BVH_BINS; j += 64) { (&s_bmin[w][0][0][0])[j] = bvh_ordered(1e30f); (&s_bmax[w][0][0][0])[j] = bvh_ordered(-1e30f); }
         float cmin[3], cmax[3];
@@ -728,12 +727,10 @@ __global__ void __launch_bounds__(64 * CRT_BVH_WAVES) crt_bvh_mid(CrtBuildNode* 
     }
 }
 
-// UpdateNodeBounds for TINY nodes: one thread per node, the sequential fold itself.
-__global__ void crt_bvh_bounds_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* __restrict__ list, uint32_t count, const CrtTri* __restrict__ tris)
+// UpdateNodeBounds for TINY nodes: one thread per node, the sequential fold itself. (round 5: called at the top of crt_bvh_tiny; as a
+// kernel of its own it was 14 launches of a 1 M-triangle build)
+__device__ __forceinline__ void bvh_bounds_tiny_body(CrtBuildNode& node, const CrtTri* __restrict__ tris)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
-    CrtBuildNode& node = nodes[list[k]];
     float mn[3] = { 1e30f, 1e30f, 1e30f }, mx[3] = { -1e30f, -1e30f, -1e30f };
     for (uint32_t i = 0; i < node.count; ++i) {
         const float* t = bvh_tri_f(tris, (size_t)node.first + i);
@@ -865,6 +862,7 @@ __global__ void crt_bvh_tiny(CrtBuildNode* __restrict__ nodes, const uint32_t* _
     const bool live = k < count;
     CrtBuildNode& node = nodes[list[live ? k : 0]];           // lanes past the end idle through the code (n = 0) so the wave stays converged
     const uint32_t first = node.first, n = live ? node.count : 0u;
+    if (live) bvh_bounds_tiny_body(node, src);
     if (bvh_wave_max(n) <= 4u) bvh_tiny_body<4>(nodes, node, live, first, n, src, dst, levelEnd, packed, next);
     else bvh_tiny_body<CRT_BVH_TINY>(nodes, node, live, first, n, src, dst, levelEnd, packed, next);
 }

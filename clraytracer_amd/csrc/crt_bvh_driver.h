@@ -89,8 +89,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         const CrtBuildLists& L = lists[p];
         if (n[0]) { crt_bvh_big_reset<<<(n[0] + 255) / 256, 256, 0, st>>>(bigs[p], n[0]);
                     crt_bvh_big_bounds<<<nChunks, T, 0, st>>>(bn, L.list[0], bigs[p], chunkNode[p], tris); }
-        if (n[1]) crt_bvh_bounds_wave<<<(n[1] + W - 1) / W, 64 * W, 0, st>>>(bn, L.list[1], n[1], tris);
-        if (n[2]) crt_bvh_bounds_tiny<<<(n[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], n[2], tris);
+        // (MID and TINY nodes compute their bounds at the top of crt_bvh_mid / crt_bvh_tiny: round 5, 26 launches fewer per 1 M-triangle build)
     };
     bounds(0, cnt, chunks, A);
     uint32_t begin = 0, end = (uint32_t)numMeshes;
