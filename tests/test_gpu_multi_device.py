@@ -244,3 +244,24 @@ def test_synchronous_frame_overlaps_the_devices_shares():
     two = sync_ms([0, 0])
     print(f"synchronous frame: one device state {one:.3f} ms, two states on the same GPU {two:.3f} ms")
     assert two < 1.6 * one, (one, two)
+
+
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
+def test_compaction_kernels_behind_several_device_states(monkeypatch, variant):
+    """The opt-in kernel structures (round 5: the wavefront form keeps frames in flight with a per-slot queue; refill / block count blocks
+    where the default kernel counts tiles) also run one share of a banded frame each: three device states, uneven bands, synchronous
+    and with frames in flight, against the single-device default kernel."""
+    sc = scenes.get("tiny")
+    w, h = 328, 200
+    monkeypatch.delenv("CRT_KERNEL", raising=False)
+    ref, ref_cnt = single_frame(sc, w, h)
+    monkeypatch.setenv("CRT_KERNEL", variant)
+    with driver.Session(w, h, devices=[0, 0, 0]) as s:
+        s.load_scene(sc)
+        s.render_raw(8)
+        assert np.array_equal(bits(s.read_output()), bits(ref)) and s.counters() == ref_cnt
+        for _ in range(7):
+            s.render_raw(4)
+        assert np.array_equal(bits(s.read_output()), bits(ref))
+        s.render_raw(0)
+        assert np.array_equal(bits(s.read_output()), bits(ref))
