@@ -2,7 +2,7 @@
 
 crt_device.h (above sphere_culls) derives the fp32 error of the object-space transform + slab tests against the
 double-precision world-space sphere and the range of ray origins |o| <= O_i for which the cull's slack
-(1.0201 r^2 + 4e-6 |oc|^2) dominates it; crt_shim.hip stores O_i per instance, never culls an instance whose O_i is below
+(1.0201 r^2 + 4e-6 |oc|^2) dominates it; crt_instances.h (rebuild_instance_master) stores O_i per instance, never culls an instance whose O_i is below
 the reach of bounce-ray origins, and runs a frame / query whose origins lie beyond the smallest O_i without the cull.
 Here: instance scales 1e-3 ... 1e3, Frobenius condition numbers to ~300, instances up to 3e5 units from the world
 origin, ray origins out to 1e6 units and to 0.95 O_i, rays that graze the bounding spheres and the corners of the boxes

@@ -228,7 +228,7 @@ def test_frames_in_flight_match_synchronous_frames(nthreads, monkeypatch, slots)
 
 
 def test_short_bursts_are_never_held_back(monkeypatch):
-    """The start-up stagger (crt_shim.hip, State::burstFrames) holds back the first frame of slots 1.. when a burst of frames in
+    """The start-up stagger (crt_state.h State::burstFrames, crt_frame.h crt1_render) holds back the first frame of slots 1.. when a burst of frames in
     flight starts on an idle device -- for a caller that STREAMS. A caller that submits two or three ASYNC frames and then reads
     would only pay it as latency: such bursts must never be held back. crt_debug_staggered_frames counts the delay
     launches, so the rule is checked exactly; the burst latency with the stagger on and forced off is printed and loosely bounded."""
