@@ -372,27 +372,31 @@ struct Traversal {
     template <class STK>
     __device__ __forceinline__ void inner(const CrtDevScene& S, const STK& stack, Closest& c, LaneCounters& lc)
     {
-        float4 lmin, lmax, rmin, rmax;
         // every lane of this step on the same node (the top of a tree under a coherent packet): one scalar load instead of four
         // vector loads, the boxes as scalar operands. (Round 2 measured the same idea as a wash -- the uniformity test costs every
         // step -- but with the instance bounds and records on the scalar path the node fetches are 3/4 of the vector-memory
         // instructions that bound the kernel: sponza-sibenik +6 %, multi-1M-dense +2 %, multi-1M and nanosuit-demo +-0, synchronous
         // frames +0...5 %. The same for leaves -- a uniform triangle through scalar loads -- lost 18 %: the 9 scalar operands push the
         // kernel into scratch, and small triangles are never shared by a whole packet.)
+        // (Round 5: the two slab tests are written out in each branch, so that the scalar branch uses the record's SGPRs as operands
+        // directly instead of copying 14 of them into VGPRs first.)
+        float dist1, dist2;
+        uint32_t nearRef, farRef;
         const uint32_t ref0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
         if (__ballot(ref != ref0) == 0) {
             const crt_const_f32x4_ptr q = (crt_const_f32x4_ptr)(S.pairs + (size_t)ref0 * 4);
             const crt_f32x4 a = q[0], b = q[1], c4 = q[2], e = q[3];
-            lmin = make_float4(a.x, a.y, a.z, a.w); lmax = make_float4(b.x, b.y, b.z, b.w);
-            rmin = make_float4(c4.x, c4.y, c4.z, c4.w); rmax = make_float4(e.x, e.y, e.z, e.w);
+            dist1 = intersect_aabb(mo, inv, make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), tr.t);
+            dist2 = intersect_aabb(mo, inv, make_float4(c4.x, c4.y, c4.z, c4.w), make_float4(e.x, e.y, e.z, e.w), tr.t);
+            nearRef = __float_as_uint(a.w); farRef = __float_as_uint(c4.w);
         } else {
             const float4* p = S.pairs + (size_t)ref * 4;        // one aligned 64-byte record
-            lmin = p[0]; lmax = p[1]; rmin = p[2]; rmax = p[3];
+            const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
+            dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
+            dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
+            nearRef = __float_as_uint(lmin.w); farRef = __float_as_uint(rmin.w);
         }
         if (COUNT) lc.innerVisits++;
-        float dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
-        float dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
-        uint32_t nearRef = __float_as_uint(lmin.w), farRef = __float_as_uint(rmin.w);
         {   // kernel_main.cl:148-151 as four selects on one compare (the branchy form costs an exec-mask save / restore)
             const bool sw = dist1 > dist2;
             const float d1 = sw ? dist2 : dist1, d2 = sw ? dist1 : dist2;
