@@ -100,7 +100,7 @@ def test_single_gpu_line_carries_the_contract_and_the_round_3_objects():
     # every BASELINE config has its rocprof HBM figure: traffic from a committed profile of exactly that workload
     for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "config3", "config2", "scale_base_n1"):
         h = d[key]["hbm"]
-        assert h is not None and h["traffic"] > 0 and 0 < h["frac"] <= 1.0 and h["traffic_source"].startswith("profiles/r05") and 0 < h["l1_hit"] < 1 and 0 < h["l2_hit"] < 1, key
+        assert h is not None and h["traffic"] > 0 and 0 < h["frac"] <= 1.0 and h["traffic_source"].startswith("profiles/r") and 0 < h["l1_hit"] < 1 and 0 < h["l2_hit"] < 1, key
     # compaction three ways, each against the default kernel in the same mode
     for key in ("wavefront_compaction", "in_wave_refill", "in_wave_block_compaction"):
         assert d[key]["vs_default_kernel_in_flight"] > 0 and d[key]["vs_default_synchronous"] > 0 and d[key]["rays_per_frame"] == d["config"]["rays_per_frame"], key
