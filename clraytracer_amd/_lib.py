@@ -66,6 +66,7 @@ HIP_API = {
     "crt_get_cull_range": (C.c_int, [_fp, C.c_int, _fp, _fp, C.POINTER(C.c_uint64)]),
     "crt_debug_staggered_frames": (C.c_int, [C.POINTER(C.c_uint64)]),
     "crt_debug_inject_failure": (C.c_int, [C.c_int]),
+    "crt_debug_last_kernel": (C.c_int, [C.c_char_p, C.c_size_t]),
     "crt_debug_measure_clock": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "crt_shutdown": (C.c_int, []),
     "crt_resize": (C.c_int, [C.c_int, C.c_int]),
@@ -200,6 +201,10 @@ def host():
         hip()
         _host = _bind(HOST_SO, HOST_API)
     return _host
+
+
+# include/crt_api.h: CrtStatus
+CRT_OK, CRT_E_NOT_INITIALIZED, CRT_E_BAD_ARGUMENT, CRT_E_OUT_OF_RANGE, CRT_E_NO_DEVICE, CRT_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 
 class CrtError(RuntimeError):

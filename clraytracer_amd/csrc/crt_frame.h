@@ -118,6 +118,10 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
 {
     *epilogueApplied = false;
     const bool count = (flags & CRT_RENDER_COUNTERS) != 0;
+    const bool stamped = (flags & CRT_RENDER_STAMPS) != 0;
+    // crt_debug_last_kernel: the Trace launch(es) of this frame under the names rocprofv3 prints for them
+    if (refill) snprintf(g.lastKernel, sizeof g.lastKernel, "%s<%d,%d>", g.refill == 2 ? "crt_trace_block_kernel" : "crt_trace_refill_kernel", stamped ? 0 : (int)count, (int)stamped);
+    else if (g.wavefront) snprintf(g.lastKernel, sizeof g.lastKernel, "crt_primary_kernel<%d>+crt_wavefront_scan_kernel+crt_bounce_kernel<%d>", (int)count, (int)count);
     if (count) HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), fs.stream));
     if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
         const size_t need = (16 + (size_t)grid * 8) * sizeof(unsigned long long);
@@ -131,7 +135,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         HIPCHK(hipMemsetAsync(g.stamps, 0, need, fs.stream));
         if (refill && g.refill == 2) crt_trace_block_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps, fs.blockQueue);
         else if (refill) crt_trace_refill_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps);
-        else crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps);
+        else { crt_trace_kernel<false, true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.stamps); snprintf(g.lastKernel, sizeof g.lastKernel, "crt_trace_kernel<0,1,0,0,0>"); }
         *epilogueApplied = true;                           // the same kernel template: F.epilogue is applied there
     } else if (refill) {                                   // in-tile lane refill (crt_refill.h); F counts blocks, not tiles
         *epilogueApplied = true;
@@ -155,6 +159,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
         const bool shadow = (flags & CRT_RENDER_SHADOWS) != 0, refract = (flags & CRT_RENDER_REFRACTION) != 0;
         // TLAS: more than CRT_TLAS_MIN_INSTANCES instances and an instance tree to walk (CRT_TLAS=0/1 forces)
         const bool tlas = S.tlasNodes > 0 && (g.forceTlas >= 0 ? (g.forceTlas != 0 && S.numInstances <= g.instHigh) : (S.numInstances > CRT_TLAS_MIN_INSTANCES && S.numInstances <= g.instHigh));      // (S.tlasNodes = 0: no tree, or a frame without the cull)
+        snprintf(g.lastKernel, sizeof g.lastKernel, "crt_trace_kernel<%d,0,%d,%d,%d>", (int)count, (int)shadow, (int)tlas, (int)refract);
 #define CRT_LAUNCH_TRACE3(C_, S_, T_, R_) crt_trace_kernel<C_, false, S_, T_, R_><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters)
 #define CRT_LAUNCH_TRACE2(C_, S_, T_) do { if (refract) CRT_LAUNCH_TRACE3(C_, S_, T_, true); else CRT_LAUNCH_TRACE3(C_, S_, T_, false); } while (0)
 #define CRT_LAUNCH_TRACE(C_, S_) do { if (tlas) CRT_LAUNCH_TRACE2(C_, S_, true); else CRT_LAUNCH_TRACE2(C_, S_, false); } while (0)
@@ -208,10 +213,18 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // diagnostic flags (they share the counters / the stamp and ray buffers) -- runs on slot 0. (Round 5: the wavefront form's queue belongs to
     // the frame slot, so it keeps frames in flight like the default kernel.)
     const bool variant = g.wavefront != 0;
-    if ((flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION)) && (variant || (flags & CRT_RENDER_STAMPS))) return CRT_E_UNSUPPORTED;   // default kernel only
-    // CRT_KERNEL=refill: the frames the refill kernel supports (one 64-bit candidate mask, no shadow rays / refraction / instance tree / diagnostics)
-    const bool refill = g.refill && !(flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION | CRT_RENDER_DIAG_MIX3))
-                     && args->numMeshes <= 64u && g.forceTlas != 1;
+    if ((flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION)) && (flags & CRT_RENDER_STAMPS)) return CRT_E_UNSUPPORTED;   // the stamped instantiation is the plain one
+    // ONE rule for the opt-in kernel forms (CRT_KERNEL=wavefront / refill / block; VERDICT r5 #1b): a frame the selected form cannot
+    // render is refused with CRT_E_UNSUPPORTED -- never rendered by another kernel behind the caller's back. What they lack: shadow rays,
+    // refraction, the three-frame diagnostic mix, the instance tree (CRT_TLAS=1); wavefront: the stamped launch; refill / block: more than
+    // 64 instances (one 64-bit candidate mask per lane).
+    if (variant || g.refill) {
+        if (flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION | CRT_RENDER_DIAG_MIX3)) return CRT_E_UNSUPPORTED;
+        if (g.forceTlas == 1) return CRT_E_UNSUPPORTED;
+        if (variant && (flags & CRT_RENDER_STAMPS)) return CRT_E_UNSUPPORTED;
+        if (g.refill && args->numMeshes > 64u) return CRT_E_UNSUPPORTED;
+    }
+    const bool refill = g.refill != 0;
     const bool fxaa = (flags & CRT_RENDER_FXAA) != 0;
     if (fxaa && g.groupSize <= 1 && g.nRanks > 1) return CRT_E_UNSUPPORTED;                  // the filter reads across band edges
     const bool pipelined = (flags & CRT_RENDER_ASYNC)

@@ -150,6 +150,14 @@ int crt_debug_inject_failure(int device)
     return CRT_OK;
 }
 int crt_debug_staggered_frames(uint64_t* out) { NEED_SESSION(); if (!out) return CRT_E_BAD_ARGUMENT; Use u_(0); *out = g.staggeredFrames; return CRT_OK; }
+int crt_debug_last_kernel(char* dst, size_t cap)
+{
+    NEED_SESSION();
+    if (!dst || cap == 0) return CRT_E_BAD_ARGUMENT;
+    Use u_(0);
+    snprintf(dst, cap, "%s", g.lastKernel);
+    return CRT_OK;
+}
 int crt_debug_measure_clock(int micros, double* ghz) { ON_PRIMARY(crt1_debug_measure_clock(micros, ghz)); }
 
 int crt_shutdown(void)

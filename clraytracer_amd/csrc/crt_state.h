@@ -94,8 +94,9 @@ struct State {
     float costSpread = 0.8f;
     float lastView[35] = { 0 }; unsigned long long lastViewInst = 0; bool viewMoved = false;   // camera matrices + position / instance version of the last sorted frame
     float splitBeta = CRT_SPLIT_BETA, splitBetaAsync = CRT_SPLIT_BETA_ASYNC;   // split a tile whose wave would run longer than beta x the XCD's time for the frame
-    int refill = 0;                            // CRT_KERNEL=refill / block: 1 = in-tile lane refill, 2 = phase-separated block compaction (crt_refill.h), for the frames they support
+    int refill = 0;                            // CRT_KERNEL=refill / block: 1 = in-tile lane refill, 2 = phase-separated block compaction (crt_refill.h), every frame (one they cannot render is refused)
     int wavefront = 0;                         // CRT_KERNEL=wavefront: one launch per bounce, ordered ballot compaction in between (crt_kernels.h)
+    char lastKernel[128] = { 0 };              // crt_debug_last_kernel: the Trace launch(es) of the most recently submitted frame
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
     bool buildNoSpin = false;                                   // the spin on buildCtlHost timed out once: synchronise the stream per level instead

@@ -70,7 +70,18 @@ static int init_impl(int device, int width, int height)
         HIPCHK(hipMemcpy(g.noCullBounds, never, sizeof never, hipMemcpyHostToDevice));
     }
     g.numCUs = prop.multiProcessorCount;
-    { const char* e = getenv("CRT_KERNEL"); g.wavefront = (e && strcmp(e, "wavefront") == 0); g.refill = (e && strcmp(e, "refill") == 0) ? 1 : ((e && strcmp(e, "block") == 0) ? 2 : 0); }  // default: megakernel (faster)
+    {   // CRT_KERNEL: the Trace kernel structure of this session. Unset / "" / "default": the megakernel (faster);
+        // "wavefront", "refill", "block": the opt-in compaction forms. Anything else is a typo, not a wish for
+        // the default: the session refuses to start (VERDICT r5 #3 -- a variant test must not pass because the name stopped matching).
+        const char* e = getenv("CRT_KERNEL");
+        g.wavefront = 0; g.refill = 0;
+        if (e && *e && strcmp(e, "default") != 0) {
+            if (strcmp(e, "wavefront") == 0) g.wavefront = 1;
+            else if (strcmp(e, "refill") == 0) g.refill = 1;
+            else if (strcmp(e, "block") == 0) g.refill = 2;
+            else { fprintf(stderr, "crt_init: CRT_KERNEL=%s is not one of default, wavefront, refill, block\n", e); return CRT_E_BAD_ARGUMENT; }
+        }
+    }
     { const char* e = getenv("CRT_SPLIT_BETA"); g.splitBeta = e ? (float)atof(e) : CRT_SPLIT_BETA; }
     { const char* e = getenv("CRT_SPLIT_BETA_ASYNC"); g.splitBetaAsync = e ? (float)atof(e) : CRT_SPLIT_BETA_ASYNC; }
     { const char* e = getenv("CRT_COST_SPREAD"); g.costSpread = e ? (float)atof(e) : 0.8f; }

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import CrtCounters, CrtError, CrtTraceArgs
+from ._lib import CrtCounters, CrtError, CrtTraceArgs  # noqa: F401 (CrtError is re-exported: driver.CrtError)
 
 
 class Session:
@@ -123,12 +123,23 @@ class Session:
         a.sunAngle = float(self.scene.sun_angle if sun_angle is None else sun_angle)
         return a, iv, ip
 
-    def render_raw(self, flags=0, sun_angle=None):
+    def render_raw(self, flags=0, sun_angle=None, view=None):
+        """crt_render with the session camera, or with explicit `view` = (invView[16], invProj[16], cameraPos[3]) (hazard H10: the
+        boundary takes the matrices, so a test may hand it ones no camera produces)."""
         a, iv, ip = self.trace_args(sun_angle)
+        if view is not None:
+            iv, ip = np.ascontiguousarray(view[0], np.float32).reshape(16), np.ascontiguousarray(view[1], np.float32).reshape(16)
+            a.cameraPos[0], a.cameraPos[1], a.cameraPos[2] = (float(x) for x in view[2])
         _lib.check(self.hip.crt_render(C.byref(a), iv.ctypes.data_as(C.POINTER(C.c_float)), ip.ctypes.data_as(C.POINTER(C.c_float)), int(flags)), "crt_render")
 
     def sync(self):
         _lib.check(self.hip.crt_sync(), "crt_sync")
+
+    def last_kernel(self):
+        """Name(s) of the Trace launch(es) of the most recently submitted frame (crt_debug_last_kernel)."""
+        buf = C.create_string_buffer(128)
+        _lib.check(self.hip.crt_debug_last_kernel(buf, len(buf)), "crt_debug_last_kernel")
+        return buf.value.decode()
 
     def read_output(self):
         out = np.empty((self.height, self.width, 4), np.float32)

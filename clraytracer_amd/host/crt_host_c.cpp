@@ -16,8 +16,9 @@ namespace { bool hostOnly = false; int hostOnlyError = 0; }
 
 extern "C" {
 
-int crth_initialize(int device, int width, int height) { hostOnly = false; return Renderer::Initialize(device, width, height); }
-int crth_initialize_devices(const int* devices, int numDevices, int width, int height) { hostOnly = false; return Renderer::InitializeDevices(devices, numDevices, width, height); }
+// (a new session starts without the last host-only session's refusal: crth_last_error used to keep reporting it)
+int crth_initialize(int device, int width, int height) { hostOnly = false; hostOnlyError = 0; return Renderer::Initialize(device, width, height); }
+int crth_initialize_devices(const int* devices, int numDevices, int width, int height) { hostOnly = false; hostOnlyError = 0; return Renderer::InitializeDevices(devices, numDevices, width, height); }
 
 int crth_initialize_host_only(int width, int height)
 {

@@ -29,6 +29,14 @@ int crt_debug_inject_failure(int device);
  * delayed by slot x latency / slots so that the slots do not run in lockstep; CRT_STAGGER_US=0 turns it off, =n forces n us). */
 int crt_debug_staggered_frames(uint64_t* out);
 
+/* Diagnostic: which Trace kernel rendered the most recently submitted frame (of the session's first device), under the name(s)
+ * rocprofv3 prints: "crt_trace_kernel<COUNT,STAMP,SHADOW,TLAS,REFRACT>" for the default megakernel, "crt_trace_refill_kernel<..>",
+ * "crt_trace_block_kernel<..>", or "crt_primary_kernel<..>+crt_wavefront_scan_kernel+crt_bounce_kernel<..>" for the opt-in forms
+ * CRT_KERNEL selects (read by crt_init; an unknown value fails crt_init). A frame the selected form cannot render is refused with
+ * CRT_E_UNSUPPORTED, never rendered by another kernel -- this query is how the tests know (tests/test_gpu_variants.py).
+ * Writes a NUL-terminated string of at most cap bytes; "" before the first frame. */
+int crt_debug_last_kernel(char* dst, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,10 @@ def test_all_flag_combinations(nthreads, monkeypatch, kind):
                 if unorm and (post or fxaa):
                     want = orc.quantize_unorm8(want)
                 s.render_raw(flags)
+                # the kernel that rendered it is the one the combination stands for (crt_debug_last_kernel)
+                want_kernel = ("crt_primary_kernel<%d>+crt_wavefront_scan_kernel+crt_bounce_kernel<%d>" % (cnt, cnt)) if plain_only else \
+                    ("crt_trace_kernel<0,1,0,0,0>" if stamps else "crt_trace_kernel<%d,0,%d,0,%d>" % (cnt, sh, rf))
+                assert s.last_kernel() == want_kernel, (flags, s.last_kernel())
                 got = s.read_output()
                 if post:                                       # powf: 2e-5; through the RGBA8 store that can move a value by one code
                     tol = (1.0 / 255.0 + 1e-6) if unorm else 2e-5

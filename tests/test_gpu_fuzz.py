@@ -59,6 +59,46 @@ def special_rays(rng, n):
     return o.astype(np.float32), d.astype(np.float32)
 
 
+def lattice_views(rng, count=4):
+    """Explicit (invView, invProj, cameraPos) triples no camera produces (the boundary takes matrices, hazard H10): the special
+    rays of special_rays() as whole FRAMES, so that every Trace kernel form -- not only crt_query_hits' own kernel -- meets
+    them. RayGen (kernel_main.cl:277-287) computes dir = normalize((invView . (invProj . (c, 1, 1) / w)).xyz) with c = pixel / size * 2 - 1;
+    with invProj = identity and an invView whose rows are signed, scaled unit vectors, a power-of-two frame gives rays from an origin on a
+    grid plane through grid points of the soups' lattice ("fan"), rays confined to an axis plane (one zero component, "plane") and frames
+    whose every ray runs along one axis (two zero components: 0 * Inf in the slab test, "axis")."""
+    views = []
+    ip = np.eye(4, dtype=np.float32)
+    for k in range(count):
+        kind = ("fan", "plane", "axis", "fan")[k % 4]
+        perm = rng.permutation(3); sign = rng.choice([-1.0, 1.0], size=3)
+        sx, sy = (float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.5, 1.0, 2.0])))
+        if kind == "plane":
+            sx = 0.0
+        if kind == "axis":
+            sx = sy = 0.0
+        iv = np.zeros((4, 4), np.float32)
+        iv[0, perm[0]] = sign[0] * sx; iv[1, perm[1]] = sign[1] * sy; iv[2, perm[2]] = sign[2]
+        pos = np.round(rng.uniform(-6, 6, size=3) * 2.0) / 2.0             # on grid planes
+        if kind != "fan":
+            pos[perm[2]] = -sign[2] * 7.0                                   # outside the soups, looking at them along the axis
+        views.append((kind, iv.reshape(16).copy(), ip.reshape(16).copy(), pos.astype(np.float32)))
+    return views
+
+
+FORMS = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<"}
+
+
+@pytest.fixture(params=list(FORMS))
+def form(request, monkeypatch):
+    """The Trace kernel structure of the session (CRT_KERNEL, read by crt_init): the default megakernel and the three opt-in
+    compaction forms. Returns (name, the prefix crt_debug_last_kernel must report)."""
+    if request.param == "default":
+        monkeypatch.delenv("CRT_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("CRT_KERNEL", request.param)
+    return request.param, FORMS[request.param]
+
+
 CASES = [  # seed, triangles per mesh, grid, instance kinds
     (1, [1, 2, 3], 3, ["plain", "mirrored", "plain"]),
     (2, [5, 17, 64], 4, ["plain", "tiny", "huge", "mirrored"]),
@@ -77,8 +117,38 @@ def build_scene(tmp_path, rng, seed, sizes, grid, kinds):
     return scenes.Scene(f"fuzz{seed}", str(tmp_path), sky, paths, insts, (0.5, 1.0, 9.0), scenes._normalize((-0.05, -0.1, -1.0)))
 
 
+def check_frames(s, orc, sc, rng, prefix, cams, flags=8, tolerated=2):
+    """Camera frames + lattice frames of the session's kernel form against the oracle: frame bits, every work counter, and the name
+    of the kernel that rendered them. Returns (frames, rays, pixels that differ within the skybox-texel tolerance, rays stopped by the cap)."""
+    frames = rays = flips = cap = 0
+    views = []
+    for cam in cams:
+        s.set_camera(cam, scenes._normalize((-cam[0] or -0.05, -0.1 if cam[1] else 0.0, -1.0 if cam[2] else 0.0)))
+        iv, ip, pos = s.camera()
+        views.append((f"camera {cam}", iv.copy(), ip.copy(), pos.copy()))
+    w0, h0 = s.width, s.height
+    for group, size in ((views, (w0, h0)), (lattice_views(rng), (256, 128))):
+        if (s.width, s.height) != size:
+            s.resize(*size)
+        for what, iv, ip, pos in group:
+            s.render_raw(flags, view=(iv, ip, pos))
+            assert s.last_kernel().startswith(prefix), (what, s.last_kernel())
+            frame = s.read_output()
+            want, fst = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle, shadows=bool(flags & 32))
+            assert s.counters() == fst, what
+            diff = np.nonzero((bits(frame) != bits(want)).any(axis=2))
+            # skybox texel flips from the double atan2/acos (glibc vs OCML) are the one tolerated difference (DESIGN.md 2)
+            assert len(diff[0]) <= tolerated, f"{what}: {len(diff[0])} pixels differ, first {diff[0][:4]},{diff[1][:4]}"
+            frames += 1; rays += fst["rays"]; flips += len(diff[0]); cap += fst["capHits"]
+    s.resize(w0, h0)
+    return frames, rays, flips, cap
+
+
 @pytest.mark.parametrize("seed,sizes,grid,kinds", CASES, ids=[f"seed{c[0]}" for c in CASES])
-def test_pathological_scenes_bit_exact(tmp_path, nthreads, seed, sizes, grid, kinds):
+def test_pathological_scenes_bit_exact(tmp_path, nthreads, form, seed, sizes, grid, kinds):
+    """Every kernel form. Explicit rays go through crt_query_hits, which has a kernel of its own and never runs a compaction form, so
+    that half is checked once (default form); the special rays reach the forms as lattice FRAMES (lattice_views)."""
+    name, prefix = form
     rng = np.random.default_rng(seed)
     sc = build_scene(tmp_path, rng, seed, sizes, grid, kinds)
     with np.errstate(all="ignore"), driver.Session(208, 120, device=0) as s:
@@ -86,22 +156,21 @@ def test_pathological_scenes_bit_exact(tmp_path, nthreads, seed, sizes, grid, ki
         a = s.arenas()
         orc = oracle_lib.Oracle(a, nthreads=nthreads)
         o, d = special_rays(rng, 8192)
-        got = s.query_hits(o, d)
-        cnt = s.counters()
-        ref, st = orc.closest_hits(o, d)
-        bad = np.nonzero(np.frombuffer(got.tobytes(), np.uint8).reshape(len(o), -1) != np.frombuffer(ref.tobytes(), np.uint8).reshape(len(o), -1))[0]
-        assert len(bad) == 0, f"{len(np.unique(bad))} hit records differ, first ray {bad[0]}: o={o[bad[0]]} d={d[bad[0]]} gpu={got[bad[0]]} oracle={ref[bad[0]]}"
-        assert cnt == st
-        for cam in ((0.5, 1.0, 9.0), (0.0, 0.0, 0.25), (-7.0, 0.0, 0.0)):    # outside, inside the soups (H1), along an axis
-            s.set_camera(cam, scenes._normalize((-cam[0] or -0.05, -0.1 if cam[1] else 0.0, -1.0 if cam[2] else 0.0)))
-            s.render_raw(8)
-            frame = s.read_output()
-            iv, ip, pos = s.camera()
-            want, fst = orc.trace(orc.raygen(s.width, s.height, iv, ip), pos, sc.sun_angle)
-            assert s.counters() == fst, cam
-            diff = np.nonzero((bits(frame) != bits(want)).any(axis=2))
-            # skybox texel flips from the double atan2/acos (glibc vs OCML) are the one tolerated difference
-            assert len(diff[0]) <= 2, f"camera {cam}: {len(diff[0])} pixels differ, first {diff[0][:4]},{diff[1][:4]}"
+        if name == "default":
+            got = s.query_hits(o, d)
+            cnt = s.counters()
+            ref, st = orc.closest_hits(o, d)
+            bad = np.nonzero(np.frombuffer(got.tobytes(), np.uint8).reshape(len(o), -1) != np.frombuffer(ref.tobytes(), np.uint8).reshape(len(o), -1))[0]
+            assert len(bad) == 0, f"{len(np.unique(bad))} hit records differ, first ray {bad[0]}: o={o[bad[0]]} d={d[bad[0]]} gpu={got[bad[0]]} oracle={ref[bad[0]]}"
+            assert cnt == st
+        # outside, inside the soups (H1), along an axis; then the lattice frames
+        frames, rays, _, _ = check_frames(s, orc, sc, rng, prefix, ((0.5, 1.0, 9.0), (0.0, 0.0, 0.25), (-7.0, 0.0, 0.0)))
+        assert frames == 7 and rays > 0
+        # frames in flight of the same form render the same bits
+        s.render_raw(0); plain = s.read_output().copy()
+        for _ in range(4):
+            s.render_raw(4)
+        assert s.last_kernel().startswith(prefix) and np.array_equal(bits(s.read_output()), bits(plain))
 
 
 @pytest.mark.parametrize("seed,sizes,grid,kinds", CASES[1:], ids=[f"seed{c[0]}" for c in CASES[1:]])

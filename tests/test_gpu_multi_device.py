@@ -258,10 +258,13 @@ def test_compaction_kernels_behind_several_device_states(monkeypatch, variant):
     monkeypatch.setenv("CRT_KERNEL", variant)
     with driver.Session(w, h, devices=[0, 0, 0]) as s:
         s.load_scene(sc)
+        prefix = {"wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<"}[variant]
         s.render_raw(8)
+        assert s.last_kernel().startswith(prefix), s.last_kernel()
         assert np.array_equal(bits(s.read_output()), bits(ref)) and s.counters() == ref_cnt
         for _ in range(7):
             s.render_raw(4)
+        assert s.last_kernel().startswith(prefix), s.last_kernel()
         assert np.array_equal(bits(s.read_output()), bits(ref))
         s.render_raw(0)
         assert np.array_equal(bits(s.read_output()), bits(ref))

@@ -7,6 +7,8 @@ from util import bits
 
 pytestmark = pytest.mark.gpu
 FLAG_COUNT = 8
+# what crt_debug_last_kernel must report for a frame of each form (the names rocprofv3 prints, profiles/r0N{wavefront,refill,block}_summary.md)
+KERNEL_OF = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<"}
 
 
 @pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
@@ -21,6 +23,7 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     with driver.Session(256, 144, device=0) as s:
         s.load_scene(sc)
         s.render_raw(FLAG_COUNT)
+        assert s.last_kernel() == "crt_trace_kernel<1,0,0,0,0>"
         ref = s.read_output(); ref_cnt = s.counters()
         # the default kernel applies the RGBA8 target / PostProcess in its epilogue ...
         fused = []
@@ -29,13 +32,16 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     monkeypatch.setenv("CRT_KERNEL", variant)
     with driver.Session(256, 144, device=0) as s:
         s.load_scene(sc)
+        assert s.last_kernel() == ""                                       # nothing rendered yet
         s.render_raw(FLAG_COUNT)
+        assert s.last_kernel().startswith(KERNEL_OF[variant]), s.last_kernel()   # not vacuous: the form really rendered the frame
         got = s.read_output(); cnt = s.counters()
         s.render_raw(0)
         got2 = s.read_output()
         # ... the variant runs them as launches of their own (crt_quantize_kernel, crt_postprocess_kernel): same bits
         for f, want in zip(stages, fused):
             s.render_raw(f)
+            assert s.last_kernel().startswith(KERNEL_OF[variant]), (f, s.last_kernel())
             assert np.array_equal(bits(s.read_output()), bits(want)), f
     assert np.array_equal(bits(got), bits(ref)) and np.array_equal(bits(got2), bits(ref))
     assert cnt == ref_cnt
@@ -59,6 +65,7 @@ def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkey
         iv, ip, pos = s.camera()
         ref, st = orc.trace(orc.raygen(1920, 1080, iv, ip), pos, sc.sun_angle)
         s.render_raw(FLAG_COUNT)
+        assert s.last_kernel().startswith(KERNEL_OF[variant]), s.last_kernel()
         got = s.read_output(); cnt = s.counters()
         assert cnt == st                                                   # rays, hits, pops, inner visits, triangle tests, max stack ...
         assert np.array_equal(bits(got[..., :3]), bits(ref[..., :3]))
@@ -68,8 +75,57 @@ def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkey
         assert np.array_equal(bits(s.read_output()), bits(got))
         for _ in range(5):
             s.render_raw(4)                                                # frames in flight
+        assert s.last_kernel().startswith(KERNEL_OF[variant]), s.last_kernel()
         assert np.array_equal(bits(s.read_output()), bits(got))
         print(f"{variant} multi-1M 1920x1080: {st['rays']} rays, {st['secondary']} compacted bounce rays, frame and counters equal to the oracle")
+
+
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
+def test_a_form_refuses_what_it_cannot_render(monkeypatch, variant):
+    """ONE rule (VERDICT r5 #1b): a frame the selected form cannot render -- shadow rays, refraction, the diagnostic mix, the stamped
+    launch (wavefront), more than 64 instances (refill / block), a forced instance tree -- returns CRT_E_UNSUPPORTED (-5) and renders
+    NOTHING: no silent fall-back to the default kernel, the last frame and its kernel name stay what they were."""
+    import ctypes as C
+    from clraytracer_amd import _lib
+    SHADOWS, REFRACT, STAMPS, MIX3, POST = 32, 256, 16, 1024, 1
+    sc = scenes.get("tiny")
+    monkeypatch.setenv("CRT_KERNEL", variant)
+    with driver.Session(256, 144, device=0) as s:
+        s.load_scene(sc)
+        s.render_raw(0)
+        name = s.last_kernel(); frame = s.read_output().copy()
+        assert name.startswith(KERNEL_OF[variant])
+        a, iv, ip = s.trace_args()
+        fp = C.POINTER(C.c_float)
+        refused = [SHADOWS, REFRACT, SHADOWS | REFRACT, SHADOWS | POST, SHADOWS | 4, MIX3] + ([STAMPS] if variant == "wavefront" else [])
+        for f in refused:
+            assert s.hip.crt_render(C.byref(a), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), f) == _lib.CRT_E_UNSUPPORTED, f
+            assert s.last_kernel() == name
+        assert np.array_equal(bits(s.read_output()), bits(frame))
+        if variant != "wavefront":
+            s.render_raw(STAMPS)                                            # refill / block have stamped instantiations of their own
+            assert s.last_kernel().startswith(KERNEL_OF[variant]) and np.array_equal(bits(s.read_output()), bits(frame))
+            a.numMeshes = 65                                                # one 64-bit candidate mask per lane
+            assert s.hip.crt_render(C.byref(a), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), 0) == _lib.CRT_E_UNSUPPORTED
+    monkeypatch.setenv("CRT_TLAS", "1")                                      # the instance tree belongs to the default kernel
+    with driver.Session(256, 144, device=0) as s:
+        s.load_scene(sc)
+        a, iv, ip = s.trace_args()
+        assert s.hip.crt_render(C.byref(a), iv.ctypes.data_as(C.POINTER(C.c_float)), ip.ctypes.data_as(C.POINTER(C.c_float)), 0) == _lib.CRT_E_UNSUPPORTED
+
+
+def test_unknown_kernel_name_fails_init(monkeypatch):
+    """CRT_KERNEL is read by crt_init; a value that names no form is a typo, not a wish for the default kernel (before round 6 it
+    silently selected the default, so a variant test could pass without its variant)."""
+    monkeypatch.setenv("CRT_KERNEL", "wavefrnt")
+    with pytest.raises(driver.CrtError):
+        driver.Session(64, 64, device=0)
+    for ok in ("", "default"):
+        monkeypatch.setenv("CRT_KERNEL", ok)
+        with driver.Session(64, 64, device=0) as s:
+            s.load_scene(scenes.get("tiny"))
+            s.render_raw(32)
+            assert s.last_kernel() == "crt_trace_kernel<0,0,1,0,0>"
 
 
 def test_stamped_launch_renders_the_same_frame():
@@ -84,6 +140,7 @@ def test_stamped_launch_renders_the_same_frame():
         for extra in (0, POST, POST | UNORM8):
             s.render_raw(extra); want = s.read_output().copy()
             s.render_raw(STAMPS | extra)
+            assert s.last_kernel() == "crt_trace_kernel<0,1,0,0,0>"
             assert np.array_equal(bits(s.read_output()), bits(want)), extra
         n = C.c_size_t(0)
         assert s.hip.crt_debug_read_stamps(None, 0, C.byref(n)) == 0 and n.value >= (256 // 8) * (144 // 8)
