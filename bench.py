@@ -366,6 +366,26 @@ def main():
         # quantised, hazard H8), 4 B per pixel
         deliver8_elapsed = delivered(flags | 128 | 64)
 
+    # one process driving N GPUs: what the gather moves per frame, and the same K frames through upstream's RGBA8 render target
+    # (CRT_RENDER_UNORM8: the secondaries send 4 B per pixel -- the bytes their Trace epilogue stores -- instead of float4 bands)
+    inproc_gather = None
+    if inproc:
+        gb, bpp = s.last_gather()
+        for _ in range(min(args.warmup, 3)):
+            _lib.check(crt_render(p_args, p_iv, p_ip, flags | 64), "crt_render")
+        _lib.check(hip.crt_sync(), "crt_sync")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rc = crt_render(p_args, p_iv, p_ip, flags | 64)
+        rc2 = hip.crt_sync()
+        dt8 = time.perf_counter() - t0
+        _lib.check(rc, "crt_render"); _lib.check(rc2, "crt_sync")
+        gb8, bpp8 = s.last_gather()
+        inproc_gather = {"gather_bytes_per_frame": gb, "bytes_per_pixel": bpp, "path": hip.crt_gather_path().decode(),
+                         "rgba8_frames": {"gather_bytes_per_frame": gb8, "bytes_per_pixel": bpp8, "ms_per_step": round(dt8 * 1e3 / args.steps, 4),
+                                          "note": "the same K frames with CRT_RENDER_UNORM8 (upstream's RGBA8 render target, Renderer.cpp:63,192): the bytes are gathered, "
+                                                  "the float frame is rebuilt on the first device only when it is read"}}
+
     tot, elapsed_max, kernel_ms_max = aggregate(dist, cnt, own_rows * width, elapsed, extent_ms, red_device, ctl)
     if sync_elapsed is not None:
         _, sync_elapsed, _ = aggregate(dist, cnt, own_rows * width, sync_elapsed, 0.0, red_device, ctl)
@@ -505,6 +525,9 @@ def main():
             out["config"]["gather_path"] = hip.crt_gather_path().decode() if inproc else "none: every rank keeps its bands (delivered_to_host* copy them to pinned host memory)"
             if inproc:
                 out["config"]["peer_access"] = [int(hip.crt_peer_access(d)) for d in range(n)]
+                ig = inproc_gather
+                ig["rgba8_frames"]["value"] = round(rays_per_frame * args.steps / (ig["rgba8_frames"]["ms_per_step"] * 1e-3 * args.steps) / 1e6, 2)
+                out["inprocess_gather"] = ig
         if sync_elapsed is not None:
             out["synchronous_frames"] = {"value": round(rays_per_frame * args.steps / sync_elapsed / 1e6, 2), "unit": "Mrays/s",
                                          "ms_per_step": round(sync_elapsed * 1e3 / args.steps, 4),

@@ -173,6 +173,41 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
     return CRT_OK;
 }
 
+// this slot's RGBA8 byte frame (4 B per pixel of the whole frame)
+static int ensure_pack(FrameSlot& fs, size_t framePixels)
+{
+    if (framePixels * 4 <= fs.packCap) return CRT_OK;
+    HIPCHK(hipStreamSynchronize(fs.stream));
+    if (fs.packBuf) (void)hipFree(fs.packBuf);
+    fs.packBuf = nullptr; fs.packCap = 0;
+    HIPCHK(hipMalloc(&fs.packBuf, framePixels * 4));
+    fs.packCap = framePixels * 4;
+    return CRT_OK;
+}
+// Multi-device session: does a frame with these flags travel to the primary as RGBA8 bytes (4 B per pixel) instead of float4 (16 B)?
+// Upstream's render target IS RGBA8 (Renderer.cpp:63,192), CRT_RENDER_UNORM8 quantises every pixel in the Trace epilogue anyway, so the
+// bytes carry the whole frame: at 8 GPUs 7 x 4.1 MB instead of 7 x 16.6 MB per 3840x2160 frame converge on the primary's links. FXAA
+// frames keep the float gather (the filter runs on the primary over the gathered Trace result).
+static bool frame_gathers_rgba8(int flags) { return g.groupSize > 1 && g.gather8 && (flags & CRT_RENDER_UNORM8) && !(flags & CRT_RENDER_FXAA); }
+// every slot's byte frame allocated (the dispatcher calls this on every device BEFORE the secondaries submit: they copy into the primary's)
+int crt1_prepare_gather8(void)
+{
+    if (!g.initialized) return CRT_E_NOT_INITIALIZED;
+    for (int i = 0; i < g.nSlots; ++i) RCCHK(ensure_pack(g.slot[i], (size_t)g.width * (size_t)g.height));
+    return CRT_OK;
+}
+// the float frame of slot `fs` from its byte frame, if the last frame on it was gathered as RGBA8 (the caller has drained the streams)
+static int expand_rgba8_frame(FrameSlot& fs)
+{
+    if (!fs.frameIs8) return CRT_OK;
+    const size_t pixels = (size_t)g.width * (size_t)g.height;
+    crt_unpack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, fs.stream>>>(fs.packBuf, fs.out, pixels);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(fs.stream));
+    fs.frameIs8 = false;
+    return CRT_OK;
+}
+
 // one wave that occupies its stream for `ticks` periods of the 100 MHz real-time counter (start-up stagger, see State::burstFrames)
 __global__ void crt_delay_kernel(unsigned long long ticks)
 {
@@ -359,14 +394,10 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     else if (fxaaLocal) F.epilogue = unorm ? CRT_EPILOGUE_QUANTIZE : 0u;
     // a read-back of the RGBA8 frame: the kernel that stores the final pixel stores its four bytes too (one device; a
     // multi-device session packs the gathered frame on its first device)
-    const bool packInKernel = unorm && (flags & CRT_RENDER_READBACK) && g.groupSize <= 1;
-    if (packInKernel && framePixels * 4 > fs.packCap) {
-        HIPCHK(hipStreamSynchronize(fs.stream));
-        if (fs.packBuf) (void)hipFree(fs.packBuf);
-        fs.packBuf = nullptr; fs.packCap = 0;
-        HIPCHK(hipMalloc(&fs.packBuf, framePixels * 4));
-        fs.packCap = framePixels * 4;
-    }
+    // ... a multi-device session's RGBA8 frame: every device's kernel stores its pixels' bytes and the BYTES are gathered (frame_gathers_rgba8)
+    const bool gather8 = frame_gathers_rgba8(flags);
+    const bool packInKernel = unorm && (((flags & CRT_RENDER_READBACK) && g.groupSize <= 1) || gather8);
+    if (packInKernel) RCCHK(ensure_pack(fs, framePixels));
     if (packInKernel && !fxaa) F.packOut = fs.packBuf;
     bool fused = false;
     if (refill) { FB.epilogue = F.epilogue; FB.packOut = F.packOut; }
@@ -389,6 +420,9 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
                 if (unorm) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
                 if (post) crt_postprocess_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
                 if (unorm && post) crt_quantize_kernel<<<grid, CRT_BLOCK, 0, fs.stream>>>(F, fs.out);
+                // RGBA8 gather behind a kernel form without the epilogue (wavefront): the bytes as a launch of their own (rows of other
+                // devices are not touched: on the primary their bytes may already have arrived)
+                if (gather8) { CrtFrame FP = F; FP.order = nullptr; FP.cost = nullptr; FP.listLen = nullptr; crt_pack_owned_kernel<<<(unsigned)F.gridBlocks, CRT_BLOCK, 0, fs.stream>>>(FP, fs.out, fs.packBuf); }
                 HIPCHK(hipGetLastError());
             }
             if (isPrimary) RCCHK(wait_for_parts());
@@ -421,9 +455,11 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         // is done with whatever the slot's previous frame still had queued (its read-back)
         FrameSlot& pfs = g.primary->slot[slot];
         HIPCHK(hipStreamWaitEvent(fs.stream, pfs.slotDone, 0));
-        RCCHK(copy_owned_rows_async(pfs.out, fs.out, 16, hipMemcpyDeviceToDevice, fs.stream));
+        if (gather8) RCCHK(copy_owned_rows_async(pfs.packBuf, fs.packBuf, 4, hipMemcpyDeviceToDevice, fs.stream));
+        else RCCHK(copy_owned_rows_async(pfs.out, fs.out, 16, hipMemcpyDeviceToDevice, fs.stream));
         HIPCHK(hipEventRecord(fs.partDone, fs.stream));
     }
+    fs.frameIs8 = gather8;
     g.cur = slot;
     es.pending = true; es.flags = flags; es.seq = ++g.frameSeq; fs.frames++;
     const bool sorted = (refill ? FB.order : F.order) != nullptr && !mix3;
@@ -449,13 +485,8 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         if (!fs.copied) HIPCHK(hipEventCreateWithFlags(&fs.copied, hipEventDisableTiming));
         const void* src = fs.out;
         if (bytes8) {
-            if (pixels * 4 > fs.packCap) {
-                if (fs.packBuf) (void)hipFree(fs.packBuf);
-                fs.packBuf = nullptr; fs.packCap = 0;
-                HIPCHK(hipMalloc(&fs.packBuf, pixels * 4));
-                fs.packCap = pixels * 4;
-            }
-            const bool packed = packInKernel && (fxaa || fused);     // the Trace (or FXAA) kernel stored the bytes already
+            RCCHK(ensure_pack(fs, pixels));
+            const bool packed = (packInKernel && (fxaa || fused)) || gather8;     // the Trace (or FXAA) kernel stored the bytes already / the byte frame was gathered
             if (!packed) crt_pack_unorm8_kernel<<<(unsigned)((pixels + 255) / 256), 256, 0, fs.stream>>>(fs.out, fs.packBuf, pixels);
             HIPCHK(hipGetLastError());
             src = fs.packBuf;
@@ -571,6 +602,7 @@ int crt1_read_output(float* dst, size_t floats)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || floats != (size_t)g.width * (size_t)g.height * 4) return CRT_E_BAD_ARGUMENT;
     RCCHK(sync_all());
+    RCCHK(expand_rgba8_frame(g.slot[g.cur]));
     HIPCHK(hipMemcpy(dst, g.slot[g.cur].out, floats * sizeof(float), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
@@ -580,6 +612,7 @@ int crt1_read_output_rows(float* dst, int row0, int rows)
     if (!g.initialized) return CRT_E_NOT_INITIALIZED;
     if (!dst || row0 < 0 || rows < 0 || row0 + rows > g.height) return CRT_E_BAD_ARGUMENT;
     RCCHK(sync_all());
+    RCCHK(expand_rgba8_frame(g.slot[g.cur]));
     HIPCHK(hipMemcpy(dst, g.slot[g.cur].out + (size_t)row0 * (size_t)g.width, (size_t)rows * (size_t)g.width * sizeof(float4), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
@@ -590,6 +623,10 @@ int crt1_read_output_rgba8(uint8_t* dst, size_t bytes)
     const size_t pixels = (size_t)g.width * (size_t)g.height;
     if (!dst || bytes != pixels * 4) return CRT_E_BAD_ARGUMENT;
     RCCHK(sync_all());
+    if (g.slot[g.cur].frameIs8) {                          // a multi-device session's RGBA8 frame: the gathered bytes ARE the frame
+        HIPCHK(hipMemcpy(dst, g.slot[g.cur].packBuf, pixels * 4, hipMemcpyDeviceToHost));
+        return CRT_OK;
+    }
     if (pixels * 4 > g.queryBytes) {                       // shares the query scratch buffer
         if (g.queryBuf) (void)hipFree(g.queryBuf);
         g.queryBuf = nullptr; g.queryBytes = 0;
@@ -629,7 +666,13 @@ int crt1_read_rays(float* dst, size_t floats)
     return CRT_OK;
 }
 
-void* crt1_output_device_ptr(void) { return g.initialized ? (void*)g.slot[g.cur].out : nullptr; }
+// (a frame gathered as RGBA8 is expanded into the float frame first: waits for the frames in flight)
+void* crt1_output_device_ptr(void)
+{
+    if (!g.initialized) return nullptr;
+    if (g.slot[g.cur].frameIs8 && (sync_all() != CRT_OK || expand_rgba8_frame(g.slot[g.cur]) != CRT_OK)) return nullptr;
+    return (void*)g.slot[g.cur].out;
+}
 
 float crt1_last_kernel_ms(int which)
 {

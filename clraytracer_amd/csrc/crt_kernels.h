@@ -531,6 +531,24 @@ __global__ void crt_pack_unorm8_kernel(const float4* __restrict__ img, uint32_t*
     out[k] = unorm8(p.x) | (unorm8(p.y) << 8) | (unorm8(p.z) << 16) | (unorm8(p.w) << 24);
 }
 
+// ... of the pixels this launch owns only (a device's share of a banded frame: the other rows of `out` belong to other devices' copies)
+__global__ __launch_bounds__(CRT_BLOCK) void crt_pack_owned_kernel(CrtFrame F, const float4* __restrict__ img, uint32_t* __restrict__ out)
+{
+    int px, py;
+    if (!lane_pixel(F, px, py)) return;
+    const size_t k = (size_t)py * (size_t)F.width + (size_t)px;
+    const float4 p = img[k];
+    out[k] = unorm8(p.x) | (unorm8(p.y) << 8) | (unorm8(p.z) << 16) | (unorm8(p.w) << 24);
+}
+// the float frame back from the bytes of the RGBA8 target: x = byte / 255 -- bit for bit what quantize1 stored (multi-device RGBA8 gather)
+__global__ void crt_unpack_unorm8_kernel(const uint32_t* __restrict__ in, float4* __restrict__ img, size_t pixels)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= pixels) return;
+    const uint32_t b = in[k];
+    img[k] = make_float4((float)(b & 255u) / 255.0f, (float)((b >> 8) & 255u) / 255.0f, (float)((b >> 16) & 255u) / 255.0f, (float)(b >> 24) / 255.0f);
+}
+
 // closest-hit query over explicit rays (hit-record parity)
 template <bool TLAS>
 __global__ __launch_bounds__(CRT_BLOCK, CRT_WAVES_PER_SIMD_COUNT) void crt_query_kernel(CrtDevScene S, const float* __restrict__ origins,

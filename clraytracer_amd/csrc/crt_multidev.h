@@ -84,6 +84,7 @@ struct Group {
     unsigned seq = 0;                           // frame-slot rotation of the session (crt_render)
     bool broken = false;                        // a resize failed on some device and could not be rolled back
     int injectFailure = -1;                     // crt_debug_inject_failure
+    unsigned long long lastGatherBytes = 0; int lastGatherBpp = 0;   // crt_debug_last_gather: what the secondaries copied into the primary for the last frame
 } M;
 
 // selects device d of the session for the calling thread; the primary is re-selected when the scope ends
@@ -107,7 +108,7 @@ static void destroy_group()
         release_all();
         delete M.dev[d]; M.dev[d] = nullptr;
     }
-    G = nullptr; M.n = 0; M.seq = 0; M.broken = false; M.injectFailure = -1;
+    G = nullptr; M.n = 0; M.seq = 0; M.broken = false; M.injectFailure = -1; M.lastGatherBytes = 0; M.lastGatherBpp = 0;
     for (int& p : M.peer) p = 0;
 }
 

@@ -150,6 +150,13 @@ int crt_debug_inject_failure(int device)
     return CRT_OK;
 }
 int crt_debug_staggered_frames(uint64_t* out) { NEED_SESSION(); if (!out) return CRT_E_BAD_ARGUMENT; Use u_(0); *out = g.staggeredFrames; return CRT_OK; }
+int crt_debug_last_gather(uint64_t* bytes, int* bytesPerPixel)
+{
+    NEED_SESSION();
+    if (bytes) *bytes = M.n > 1 ? M.lastGatherBytes : 0;
+    if (bytesPerPixel) *bytesPerPixel = M.n > 1 ? M.lastGatherBpp : 0;
+    return CRT_OK;
+}
 int crt_debug_last_kernel(char* dst, size_t cap)
 {
     NEED_SESSION();
@@ -218,6 +225,16 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     RenderPlan plan;
     { Use u(0); plan.slot = frame_is_pipelined(flags) ? (int)(M.seq++ % (unsigned)g.nSlots) : 0; }
     plan.noHostWait = true;
+    // RGBA8 frames travel as bytes (frame_gathers_rgba8): every device's byte frames exist before a secondary copies into the primary's
+    bool gather8 = false;
+    { Use u(0); gather8 = frame_gathers_rgba8(flags); }
+    if (gather8) for (int d = 0; d < M.n; ++d) { Use u(d); RCCHK(crt1_prepare_gather8()); }
+    {   // what the secondaries send into the primary for this frame (crt_debug_last_gather)
+        Use u(0);
+        unsigned long long rows = 0;
+        for (int d = 1; d < M.n; ++d) { const BandPlan p = band_plan(g.height, g.bandRows, d, M.n); rows += (unsigned long long)p.fullBands * (unsigned)g.bandRows + (unsigned)p.tailRows; }
+        M.lastGatherBpp = gather8 ? 4 : 16; M.lastGatherBytes = rows * (unsigned long long)g.width * (unsigned)M.lastGatherBpp;
+    }
     // secondaries first, each on its own worker thread (they record the events the primary's stream then waits on) and
     // without waiting for their devices; their copy of the frame never leaves the device except through the gather, so
     // READBACK is the primary's business

@@ -41,6 +41,10 @@ struct FrameSlot {
     // in-process multi-GPU (crt_init_devices): a secondary device records `partDone` behind the copy of its bands into the
     // primary's frame; the primary records `slotDone` behind everything a frame queues on this slot (incl. a read-back)
     hipEvent_t partDone = nullptr, slotDone = nullptr;
+    // RGBA8 gather (a multi-device session's CRT_RENDER_UNORM8 frames without FXAA): the WHOLE frame is in packBuf (every device's Trace
+    // epilogue stores its pixels' four bytes, the secondaries copy 4 B per pixel into the primary's packBuf); `out` holds only this
+    // device's bands until somebody asks for the float frame (expand_rgba8_frame: x = byte / 255, exactly what the epilogue stored)
+    bool frameIs8 = false;
 };
 
 struct State {
@@ -112,6 +116,7 @@ struct State {
     double frameLog[512]; unsigned frameLogN = 0;      // crt_debug_read_frame_times: {start, end} ms after statStart of the frames since the last reset
     // in-process multi-GPU: this device renders band `rank` of `nRanks`; `primary` (rank 0) owns the frame that is read
     State* primary = nullptr; State* group[CRT_MAX_DEVICES] = { nullptr }; int groupSize = 1;
+    int gather8 = 1;                           // CRT_GATHER_RGBA8=0: gather float4 bands even for CRT_RENDER_UNORM8 frames (A/B, tests)
 };
 // One State per device (crt_init: one; crt_init_devices: one per GPU). Every function below works on "the current
 // device's state" through `g`; the dispatch layer at the end of the file selects it (and the HIP device) per call, on the

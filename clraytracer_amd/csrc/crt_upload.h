@@ -88,6 +88,7 @@ static int init_impl(int device, int width, int height)
     { const char* e = getenv("CRT_SPLIT");               // tuning knob: cap on quadrant-split tiles per XCD (both modes)
       if (e) { int v = atoi(e); v = v < 0 ? 0 : (v > CRT_MAX_SPLIT ? CRT_MAX_SPLIT : v); g.maxSplit = g.maxSplitPipelined = v; }
       else { g.maxSplit = CRT_MAX_SPLIT; g.maxSplitPipelined = CRT_MAX_SPLIT_PIPELINED; } }
+    { const char* e = getenv("CRT_GATHER_RGBA8"); g.gather8 = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_TLAS"); g.forceTlas = e ? (atoi(e) != 0 ? 1 : 0) : -1; }
     { const char* e = getenv("CRT_STAGGER_US"); g.staggerUs = e ? atoi(e) : -1; }
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }

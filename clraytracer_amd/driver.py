@@ -146,6 +146,18 @@ class Session:
         _lib.check(self.hip.crt_read_output(out.ctypes.data, out.size), "crt_read_output")
         return out
 
+    def read_output_rgba8(self):
+        """The frame as the bytes of upstream's RGBA8 render target (crt_read_output_rgba8)."""
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        _lib.check(self.hip.crt_read_output_rgba8(out.ctypes.data, out.size), "crt_read_output_rgba8")
+        return out
+
+    def last_gather(self):
+        """(bytes, bytes per pixel) the secondary devices sent to the first device for the last frame (crt_debug_last_gather)."""
+        b, bpp = C.c_uint64(0), C.c_int(0)
+        _lib.check(self.hip.crt_debug_last_gather(C.byref(b), C.byref(bpp)), "crt_debug_last_gather")
+        return int(b.value), int(bpp.value)
+
     def read_rays(self):
         out = np.empty((self.height, self.width, 3), np.float32)
         _lib.check(self.hip.crt_read_rays(out.ctypes.data, out.size), "crt_read_rays")

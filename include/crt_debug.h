@@ -36,6 +36,12 @@ int crt_debug_staggered_frames(uint64_t* out);
  * CRT_E_UNSUPPORTED, never rendered by another kernel -- this query is how the tests know (tests/test_gpu_variants.py).
  * Writes a NUL-terminated string of at most cap bytes; "" before the first frame. */
 int crt_debug_last_kernel(char* dst, size_t cap);
+/* Diagnostic (crt_init_devices sessions): what the secondary devices copied into the first device for the most recently submitted
+ * frame -- *bytes in total, *bytesPerPixel 16 (float4 bands) or 4: a CRT_RENDER_UNORM8 frame without FXAA is gathered as the bytes of
+ * upstream's RGBA8 render target (Renderer.cpp:63,192), which every device's Trace epilogue stores beside the float pixel; the
+ * float frame is rebuilt from them (x = byte / 255, bit for bit) only when crt_read_output / crt_output_device_ptr ask for it.
+ * CRT_GATHER_RGBA8=0 in the environment keeps the float4 gather. 0 / 0 in a one-device session. */
+int crt_debug_last_gather(uint64_t* bytes, int* bytesPerPixel);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,11 @@ def test_in_process_two_device_states():
     assert d["config"]["peer_access"] == [2, 2] and "same-device" in d["config"]["gather_path"]
     assert "crt_init_devices" in d["config"]["tiling"] and d["config"]["control_plane"] in (None, "gloo")
     assert d["synchronous_frames"]["value"] > 0
+    # the gather: float4 bands for the plain frames of the timed region, the bytes of upstream's RGBA8 target for UNORM8 frames
+    g = d["inprocess_gather"]
+    rows = sum(1 for y in range(2160) if (y // 16) % 2 == 1)
+    assert (g["gather_bytes_per_frame"], g["bytes_per_pixel"]) == (rows * 3840 * 16, 16)
+    assert (g["rgba8_frames"]["gather_bytes_per_frame"], g["rgba8_frames"]["bytes_per_pixel"]) == (rows * 3840 * 4, 4) and g["rgba8_frames"]["value"] > 0
 
 
 def test_in_process_eight_device_states():
@@ -51,6 +56,8 @@ def test_in_process_eight_device_states():
     check_common(d, 8)
     assert d["config"]["peer_access"] == [2] * 8 and d["config"]["frames_in_flight"] == 8
     assert d["imbalance_max_over_mean"] is None                             # one process: no per-rank clocks
+    rows = sum(1 for y in range(2160) if (y // 16) % 8 != 0)
+    assert d["inprocess_gather"]["rgba8_frames"]["gather_bytes_per_frame"] == rows * 3840 * 4      # 7 x 4.1 MB instead of 7 x 16.6 MB
 
 
 @pytest.mark.parametrize("ranks", [2, 4])

@@ -268,3 +268,76 @@ def test_compaction_kernels_behind_several_device_states(monkeypatch, variant):
         assert np.array_equal(bits(s.read_output()), bits(ref))
         s.render_raw(0)
         assert np.array_equal(bits(s.read_output()), bits(ref))
+
+
+@pytest.mark.parametrize("ndev", [2, 8])
+def test_rgba8_frames_are_gathered_as_bytes(ndev, monkeypatch):
+    """a CRT_RENDER_UNORM8 frame (upstream's render target is RGBA8, Renderer.cpp:63,192) travels to the first device as the
+    4 bytes per pixel every device's Trace epilogue stores, not as float4 bands: the gathered byte frame, the float frame rebuilt from it on
+    demand (x = byte / 255), the read-back and frames in flight all equal the single-device RGBA8 frame bit for bit; plain and FXAA frames
+    keep the float gather; crt_debug_last_gather reports the bytes; CRT_GATHER_RGBA8=0 gives the old path and the same frames."""
+    UNORM8, POST, ASYNC, READBACK, FXAA = 64, 1, 4, 128, 512
+    sc = scenes.get("tiny")
+    w, h = 328, 200
+    monkeypatch.delenv("CRT_GATHER_RGBA8", raising=False)
+    ref = {}
+    with driver.Session(w, h, device=0) as s:
+        s.load_scene(sc)
+        assert s.last_gather() == (0, 0)
+        for f in (0, UNORM8, UNORM8 | POST, UNORM8 | FXAA):
+            s.render_raw(f)
+            ref[f] = (s.read_output().copy(), s.read_output_rgba8().copy())
+    assert not np.array_equal(ref[UNORM8][1], ref[UNORM8 | POST][1])
+    rows_sent = sum(1 for y in range(h) if (y // 16) % ndev != 0)         # rows the secondaries own
+    ptr, nbytes = C.c_void_p(), C.c_size_t()
+    for env in (None, "0"):
+        if env is not None:
+            monkeypatch.setenv("CRT_GATHER_RGBA8", env)
+        with driver.Session(w, h, devices=[0] * ndev) as s:
+            s.load_scene(sc)
+            for f in (UNORM8, UNORM8 | POST):
+                s.render_raw(f)
+                assert s.last_gather() == ((rows_sent * w * 4, 4) if env is None else (rows_sent * w * 16, 16)), (f, s.last_gather())
+                assert np.array_equal(s.read_output_rgba8(), ref[f][1]), f             # the gathered bytes ARE the frame
+                assert np.array_equal(bits(s.read_output()), bits(ref[f][0])), f       # float frame rebuilt on demand
+                assert np.array_equal(s.read_output_rgba8(), ref[f][1]), f             # ... and the bytes once more, after the rebuild
+                for _ in range(7):
+                    s.render_raw(f | ASYNC)                                            # slots rotate on every device in step
+                assert np.array_equal(s.read_output_rgba8(), ref[f][1]), f
+                s.render_raw(f | READBACK)
+                assert s.hip.crt_map_host_frame(C.byref(ptr), C.byref(nbytes)) == 0 and nbytes.value == w * h * 4
+                host = np.frombuffer((C.c_char * nbytes.value).from_address(ptr.value), np.uint8).reshape(h, w, 4)
+                assert np.array_equal(host, ref[f][1]), f
+            # what follows an RGBA8 frame on the same slot: plain and filtered frames gather float4 bands as before
+            for f in (0, UNORM8 | FXAA):
+                s.render_raw(f)
+                assert s.last_gather() == (rows_sent * w * 16, 16)
+                assert np.array_equal(bits(s.read_output()), bits(ref[f][0])), f
+            s.render_raw(UNORM8)
+            assert np.array_equal(bits(s.read_output()), bits(ref[UNORM8][0]))
+            # through the mirrored Renderer: SetUnorm8 + MapOutputRGBA8
+            s.h.crth_set_unorm8(1)
+            s.render(postprocess=True)
+            got = _lib.as_array(s.h.crth_map_output_rgba8(), w * h * 4, np.uint8).reshape(h, w, 4)
+            assert np.array_equal(got, ref[UNORM8 | POST][1])
+            s.h.crth_set_unorm8(0)
+
+
+def test_rgba8_gather_behind_the_wavefront_form(monkeypatch):
+    """The wavefront form has no epilogue: its devices pack the bytes of the rows they own in a launch of their own (crt_pack_owned_kernel),
+    never touching rows whose bytes other devices may already have delivered."""
+    UNORM8, POST = 64, 1
+    sc = scenes.get("tiny")
+    w, h = 328, 200
+    monkeypatch.delenv("CRT_KERNEL", raising=False)
+    with driver.Session(w, h, device=0) as s:
+        s.load_scene(sc)
+        s.render_raw(UNORM8 | POST)
+        ref = s.read_output_rgba8().copy()
+    monkeypatch.setenv("CRT_KERNEL", "wavefront")
+    with driver.Session(w, h, devices=[0, 0, 0]) as s:
+        s.load_scene(sc)
+        for _ in range(3):
+            s.render_raw(UNORM8 | POST)
+            assert s.last_kernel().startswith("crt_primary_kernel<") and s.last_gather()[1] == 4
+            assert np.array_equal(s.read_output_rgba8(), ref)
