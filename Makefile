@@ -12,7 +12,7 @@ CXXFLAGS = -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -
 
 HIP_SO = clraytracer_amd/csrc/libcrt_hip.so
 HOST_SO = clraytracer_amd/host/libcrt_host.so
-HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp MeshCache.cpp JpegDecode.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp)
+HOST_SRC = $(addprefix clraytracer_amd/host/,AssetManager.cpp MeshCache.cpp JpegDecode.cpp BVH.cpp CPURayTrace.cpp Renderer.cpp ResourceManager.cpp crt_host_c.cpp ShmBarrier.cpp)
 HOST_HDR = $(wildcard clraytracer_amd/host/*.hpp) $(wildcard include/*.h)
 
 EXAMPLE = examples/crt_headless
@@ -40,7 +40,7 @@ $(HIP_SO): $(wildcard clraytracer_amd/csrc/*.h) clraytracer_amd/csrc/crt_shim.hi
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ clraytracer_amd/csrc/crt_shim.hip
 
 $(HOST_SO): $(HOST_SRC) $(HOST_HDR) $(HIP_SO)
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -Lclraytracer_amd/csrc -lcrt_hip -Wl,-rpath,'$$ORIGIN/../csrc'
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -Lclraytracer_amd/csrc -lcrt_hip -lrt -Wl,-rpath,'$$ORIGIN/../csrc'
 
 oracle:
 	$(MAKE) -C oracle

@@ -227,9 +227,20 @@ def main():
     pair_fetches = cnt["innerVisits"] - int(culled.value)        # child-pair records the device really fetches per frame
     own_rows = s.owned_rows()
 
+    # The barrier that brackets the timed regions. All ranks of the contract run on one node, so they meet in shared memory
+    # (clraytracer_amd/node_barrier.py, host/ShmBarrier.cpp): a rank leaves within a cache-line transfer of the last arrival, where a gloo /
+    # RCCL barrier's latency and exit skew (0.1-0.3 ms idle, milliseconds on a loaded host: tools/barrier_cost.py) would be counted as rendering
+    # time of a 2.6 ms region (N = 8: 20 x 0.13 ms). Ranks on different hosts, or CRT_BENCH_SHM_BARRIER=0, keep torch.distributed's barrier.
+    node_barrier = None
+    if dist is not None and world > 1 and os.environ.get("CRT_BENCH_SHM_BARRIER", "1") != "0":
+        from clraytracer_amd.node_barrier import NodeBarrier
+        node_barrier = NodeBarrier.create(dist)
+
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
+        if node_barrier is not None:
+            node_barrier.wait()
+        elif dist is not None:
             dist.barrier(group=ctl)
         torch.cuda.synchronize()
 
@@ -241,20 +252,6 @@ def main():
     crt_render = hip.crt_render
     flags = (4 if flight > 1 else 0) | (32 if args.shadows else 0) | (1024 if args.diag_mix3 else 0)   # CRT_RENDER_ASYNC, CRT_RENDER_SHADOWS, CRT_RENDER_DIAG_MIX3
     stats = _lib.CrtFrameStats()
-
-    # N > 1: the same workload on ONE GPU (this rank renders the whole frame, untimed by the contract clock), so the
-    # line carries its own strong-scaling reference next to the N-GPU value
-    if n > 1 and rank == 0 and not inproc:
-        s.set_row_bands(args.band_rows, 0, 1)
-        for _ in range(3):
-            _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
-        _lib.check(hip.crt_sync(), "crt_sync")
-        t0 = time.perf_counter()
-        for _ in range(10):
-            rc = crt_render(p_args, p_iv, p_ip, flags)
-        _lib.check(hip.crt_sync(), "crt_sync")
-        single = (time.perf_counter() - t0) / 10
-        s.set_row_bands(args.band_rows, rank, n)
 
     # Clock pre-warm (untimed, before the W warm-up steps): the box hands over an idle GPU at its idle clocks, and W = 5 frames
     # (1.5 ms) do not bring them up -- a 20-step timed region right behind them measured the DVFS ramp (5.85 ms of device time
@@ -285,6 +282,23 @@ def main():
     # steady state: the first frame's latency is the pipeline's fill time; what follows it is K - 1 frames at the steady cadence.
     # A 20-step run and a 200-step run agree on this figure; the contract's `value` includes the fill.
     steady_ms = (stats.extentMs - stats.firstFrameMs) / max(1, stats.frames - 1) if stats.frames > 1 else extent_ms
+
+    # N > 1: the same workload on ONE GPU -- rank 0 renders the whole frame, untimed by the contract clock, while the others wait at the
+    # next barrier -- so the line carries its own strong-scaling reference. Like for like (r6): the same region shape as the timed one
+    # (W warm-up frames, K frames + sync, fill included) on clocks the timed region has just warmed; rounds 1-5 timed 3 + 10 frames
+    # BEFORE the pre-warm, which under-read the single GPU (11.1-11.5 vs 12.3 Gray/s) and so flattered the speed-up by 7-10 %.
+    if n > 1 and rank == 0 and not inproc:
+        s.set_row_bands(args.band_rows, 0, 1)
+        for _ in range(max(args.warmup, 3)):
+            _lib.check(crt_render(p_args, p_iv, p_ip, flags), "crt_render")
+        _lib.check(hip.crt_sync(), "crt_sync")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rc = crt_render(p_args, p_iv, p_ip, flags)
+        _lib.check(hip.crt_sync(), "crt_sync")
+        single = (time.perf_counter() - t0) / args.steps
+        s.set_row_bands(args.band_rows, rank, n)
+        _lib.check(hip.crt_frame_time_stats(None, 1), "crt_frame_time_stats")
 
     def measure_view(sess, vflags, frames, label):
         """An extra view / flag set outside the contract's timed region: counted launch for the rays, then `frames` frames."""
@@ -465,7 +479,9 @@ def main():
                        "tiling": (f"16-row bands round-robin over {n} devices driven by ONE process (crt_init_devices {inproc_devices}), replicated scene, "
                                   "every frame gathered into device 0 by peer copies inside the timed region") if inproc
                                  else f"{args.band_rows}-row bands round-robin over {n} rank(s), replicated scene",
-                       "frames_in_flight": flight, "control_plane": control_plane, "diag_mix3": bool(args.diag_mix3), "prewarm_ms": args.prewarm_ms,
+                       "frames_in_flight": flight, "control_plane": control_plane,
+                       "barrier": None if dist is None else ("shared-memory node barrier (host/ShmBarrier.cpp) between torch.cuda.synchronize() calls; group set-up and reductions over " + str(control_plane)
+                                                            if node_barrier is not None else "torch.distributed barrier over " + str(control_plane)), "diag_mix3": bool(args.diag_mix3), "prewarm_ms": args.prewarm_ms,
                        "stagger": {"mode": ("CRT_STAGGER_US=" + os.environ["CRT_STAGGER_US"]) if "CRT_STAGGER_US" in os.environ
                                            else "automatic: the first frame of slots 1.. of a burst that follows a burst longer than the slot count is held back by slot x latency / slots (up to 3 slots)",
                                    "frames_held_back_in_session": staggered_frames},
@@ -541,7 +557,9 @@ def main():
                                               "note": "the same with the frame taken through upstream's RGBA8 render target (CRT_RENDER_UNORM8): 4 B per pixel instead of 16"}
         if single is not None:
             out["single_gpu_same_workload"] = {"value": round(rays_per_frame / single / 1e6, 2), "unit": "Mrays/s",
-                                               "ms_per_step": round(single * 1e3, 4), "note": "rank 0 alone rendering the whole frame, 10 frames, same mode"}
+                                               "ms_per_step": round(single * 1e3, 4),
+                                               "note": "rank 0 alone rendering the whole frame right after the timed region: the same region shape (W warm-up frames, K frames + sync, same frames in flight)"
+                                                       if not inproc else "one device alone rendering the whole frame, 3 + 10 frames, same mode"}
             out["speedup_vs_single_gpu_same_workload"] = round(value / (rays_per_frame / single / 1e6), 3)
         if n > 1:
             out["per_rank_ms_per_step"] = [round(x, 4) for x in rank_ms]

@@ -168,6 +168,9 @@ HOST_API = {
     "crth_perspective_fov_rh": (None, [_f, _f, _f, _f, _f, _fp]),
     "crth_look_at_rh": (None, [_fp, _fp, _fp, _fp]),
     "crth_write_obj": (C.c_int, [C.c_char_p, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "crth_shm_barrier_open": (_vp, [C.c_char_p, C.c_int, C.c_int]),
+    "crth_shm_barrier_wait": (C.c_int, [_vp, C.c_int]),
+    "crth_shm_barrier_close": (None, [_vp]),
 }
 
 

@@ -93,6 +93,14 @@ int crth_write_obj(const char* path, const float* positions, int numPositions, c
                    const float* normals, int numNormals, const int* faces, const int* faceMaterial, int numFaces,
                    const char* const* materialNames, int numMaterials);
 
+/* A barrier for the ranks of ONE node in POSIX shared memory (no reference counterpart; host/ShmBarrier.cpp): bench.py brackets its timed
+ * region with it so that a TCP / collective barrier's latency and exit skew are not counted as rendering time. `name` starts with '/';
+ * one rank creates (create = 1) before the others open; crth_shm_barrier_wait returns 0, or -1 when not every rank arrived within
+ * timeoutMs (the caller must give up: the barrier is then unusable); close unlinks the object on the creating rank. */
+void* crth_shm_barrier_open(const char* name, int nRanks, int create);
+int crth_shm_barrier_wait(void* handle, int timeoutMs);
+void crth_shm_barrier_close(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

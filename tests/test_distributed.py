@@ -156,3 +156,58 @@ def test_two_rank_gather_follows_the_band_plan(tmp_path):
     mp.spawn(_gather_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "gathered.npy")
     assert np.array_equal(got, np.arange(90 * 40 * 4, dtype=np.float32).reshape(90, 40, 4))
+
+
+def _node_barrier_worker(rank, world, port, outdir):
+    """bench.py's timed-region bracket on CPU ranks: the shared-memory node barrier set up over the gloo group. A shared counter that is only
+    consistent if nobody passes barrier k before everybody has arrived at it; then the timing pattern of the bench (barrier, t0, work, barrier, t1)."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clraytracer_amd.node_barrier import NodeBarrier
+        nb = NodeBarrier.create(dist, timeout_ms=20000)
+        assert nb is not None                                        # both ranks run on this host
+        log = np.lib.format.open_memmap(os.path.join(outdir, "log.npy"), mode="r+")
+        for k in range(200):
+            log[rank, k] = k + 1                                     # "I have arrived at barrier k"
+            if rank == 1 and k % 50 == 0:
+                time.sleep(0.002)                                    # a straggler
+            nb.wait()
+            assert log[1 - rank, k] == k + 1, (rank, k)              # ... and so has the other rank, before I leave it
+        over = []
+        for _ in range(50):
+            nb.wait(); t0 = time.perf_counter()
+            t_end = t0 + 0.001
+            while time.perf_counter() < t_end:
+                pass
+            nb.wait(); over.append(time.perf_counter() - t0 - 0.001)
+        np.save(os.path.join(outdir, f"over{rank}.npy"), np.array(over))
+        nb.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_node_barrier_between_two_ranks(tmp_path):
+    world = 2
+    port = 29300 + (os.getpid() % 500)
+    np.save(tmp_path / "log.npy", np.zeros((2, 200), np.int64))
+    mp.spawn(_node_barrier_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    over = np.concatenate([np.load(tmp_path / f"over{r}.npy") for r in range(world)])
+    assert np.median(over) < 200e-6, np.median(over)                  # microseconds, not a TCP round trip (bound loose: CI hosts are busy)
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("crt_bench_")]      # the creating rank unlinked the object
+
+
+def test_node_barrier_times_out_instead_of_hanging():
+    """Every wait has a deadline: a rank that died cannot hang the others (the barrier returns -1 and the caller gives up loudly)."""
+    sys.path.insert(0, ROOT)
+    from clraytracer_amd import _lib
+    h = _lib.host()
+    name = f"/crt_test_timeout_{os.getpid()}".encode()
+    a = h.crth_shm_barrier_open(name, 2, 1)
+    assert a and h.crth_shm_barrier_open(name, 3, 0) is None          # rank-count mismatch is refused
+    assert h.crth_shm_barrier_wait(a, 30) == -1                       # the second rank never comes
+    h.crth_shm_barrier_close(a)
+    assert h.crth_shm_barrier_open(name, 2, 0) is None                # unlinked

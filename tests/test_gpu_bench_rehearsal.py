@@ -68,6 +68,8 @@ def test_ranks_under_torch_distributed_run(ranks):
                    "--master-port", str(29571 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--prewarm-ms", "5"])
     check_common(d, ranks)
     assert d["config"]["control_plane"] == "gloo"                           # the rehearsal never uses RCCL (all ranks sit on GPU 0)
+    assert d["config"]["barrier"].startswith("shared-memory node barrier")  # the timed regions are bracketed in shared memory, not over TCP
+    assert "same region shape" in d["single_gpu_same_workload"]["note"] and d["speedup_vs_single_gpu_same_workload"] > 0
     assert d["delivered_to_host"]["value"] > 0 and d["delivered_to_host_rgba8"]["value"] > 0
     assert f"16-row bands round-robin over {ranks} rank(s)" in d["config"]["tiling"]
     assert d["config"]["frames_in_flight"] == (3 if ranks < 4 else 8)
