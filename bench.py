@@ -679,7 +679,10 @@ def main():
                 for key, variant, label in ((None, "default", "crt_trace_kernel (the default megakernel)"),
                                             ("wavefront_compaction", "wavefront", "crt_primary_kernel -> compaction -> crt_bounce_kernel"),
                                             ("in_wave_refill", "refill", "crt_trace_refill_kernel: in-tile lane refill, 16x8 blocks"),
-                                            ("in_wave_block_compaction", "block", "crt_trace_block_kernel: classify -> dense primary packets -> dense bounce packets, 16x8 blocks")):
+                                            ("in_wave_block_compaction", "block", "crt_trace_block_kernel: classify -> dense primary packets -> dense bounce packets, 16x8 blocks"),
+                                            # north_star's "hot BVH tiles staged in LDS" (round 6; crt_ldstop.h): four-wave workgroups sharing a 15.75 KiB LDS copy of
+                                            # every mesh's top tree levels, 15 stack slots per wave in LDS, 5 waves per SIMD instead of 8
+                                            ("lds_tree_tops", "ldstop", "crt_trace_ldstop_kernel: 4 tiles per workgroup, the trees' top levels (252 pair records) staged in LDS")):
                     os.environ["CRT_KERNEL"] = variant
                     with driver.Session(width, height, device=device_index) as sw:
                         sw.load_scene(sc)

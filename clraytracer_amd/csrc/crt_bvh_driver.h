@@ -84,6 +84,24 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     crt_bvh_init_roots<<<1, 1, 0, st>>>(bn, dCounts, numMeshes, (uint32_t)firstTri, bigs[0], chunkNode[0]);
     HIPCHK(hipGetLastError());
 
+    // Measurement hook (CRT_DEBUG_HOOKS=1 + CRT_DEBUG_BVH_REPLAY=1): the builder is deterministic, so a build of the SAME input can
+    // take every level's list sizes from a recording of the previous one and enqueue all its launches back to back -- exact grids, no publish
+    // kernel, no host round trip per level. That is the floor of ANY one-submission scheme (a HIP graph re-launched with device-read grid sizes,
+    // a persistent kernel with a device-side level counter): what `crt_build_bvh` would take if the level hand-shake cost nothing.
+    // (The caller must rebuild the SAME triangles -- tools/bvh_build_time.py does; the key covers only the mesh sizes. A mismatch ends in
+    // CRT_E_OUT_OF_RANGE at the final node-count check.)
+    bool replaying = false, recording = false;
+    {
+        const char* h = getenv("CRT_DEBUG_HOOKS"); const char* r = getenv("CRT_DEBUG_BVH_REPLAY");
+        if (h && atoi(h) != 0 && r && atoi(r) != 0) {
+            unsigned long long key = 1469598103934665603ull;                        // FNV-1a over what determines the level structure besides the triangles themselves
+            auto mix = [&](unsigned long long v) { for (int b = 0; b < 8; ++b) { key ^= (v >> (8 * b)) & 0xFFu; key *= 1099511628211ull; } };
+            mix(firstTri); mix(total); mix((unsigned long long)numMeshes);
+            for (int m = 0; m < numMeshes; ++m) mix(meshTriCounts[m]);
+            replaying = !g.buildReplay.empty() && g.buildReplayKey == key;
+            if (!replaying) { g.buildReplay.clear(); g.buildReplayKey = key; recording = true; }
+        } else g.buildReplay.clear();
+    }
     const unsigned W = CRT_BVH_WAVES, T = CRT_BVH_BIG_THREADS;
     auto bounds = [&](int p, const uint32_t n[3], uint32_t nChunks, const CrtTri* tris) {
         const CrtBuildLists& L = lists[p];
@@ -112,7 +130,11 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         if (cnt[1]) crt_bvh_mid<<<(cnt[1] + W - 1) / W, 64 * W, 0, st>>>(bn, L.list[1], cnt[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, &dCtl->packed, N);
         if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, &dCtl->packed, N);
         HIPCHK(hipGetLastError());
-        {   // the level's list sizes: published into pinned memory behind the level's kernels; spin on the sequence number (a copy + stream
+        if (replaying && (size_t)(level - 1) < g.buildReplay.size()) {
+            // measurement hook (below): the level's list sizes are known from the recorded build of the same input -- no publish, no wait
+            ctl = g.buildReplay[(size_t)(level - 1)];
+        } else {
+            // the level's list sizes: published into pinned memory behind the level's kernels; spin on the sequence number (a copy + stream
             // synchronisation per level cost ~40 us x 23 levels of a 1 M-triangle build), fall back to the stream if it does not arrive
             const uint32_t seq = ++g.buildSeq;
             crt_bvh_publish<<<1, 1, 0, st>>>(dCtl, g.buildCtlHost, seq);
@@ -120,17 +142,25 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
             bool arrived = false;
             for (unsigned spin = 0; spin < (1u << 22) && !g.buildNoSpin; ++spin) {
                 if (g.buildCtlHost->seq == seq) { arrived = true; break; }
-                if ((spin & 0x3FFu) == 0x3FFu && hipStreamQuery(st) != hipErrorNotReady) break;      // finished (or failed) without our flag: let the sync below sort it out
+                if ((spin & 0x3FFu) == 0x3FFu && hipStreamQuery(st) != hipErrorNotReady) {
+                    // finished (or failed) between two looks at the flag: the record may have landed in that window -- look once more
+                    // before blaming coherence; a failed stream is sorted out by the synchronisation below
+                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                    arrived = g.buildCtlHost->seq == seq;
+                    break;
+                }
                 crt_cpu_relax();
             }
             if (!arrived) {
-                // the record did not become visible while the level ran (host memory that is not coherent with running kernels): from now on
-                // wait for the stream at once instead of burning the spin budget on every level
                 HIPCHK(hipStreamSynchronize(st)); if (g.buildCtlHost->seq != seq) return CRT_E_UNSUPPORTED;
+                // Latched only when the record really was invisible while the level ran: the spin budget ran out with the stream still busy, or
+                // the stream had drained and the record was STILL stale at the re-read above (host memory not coherent with running kernels).
+                // From then on wait for the stream at once instead of burning the spin budget on every level.
                 if (!g.buildNoSpin) { g.buildNoSpin = true; fprintf(stderr, "[crt] crt_build_bvh: the pinned control record is not visible before the stream drains; using stream synchronisation per level\n"); }
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             ctl = g.buildCtlHost->ctl;
+            if (recording) g.buildReplay.push_back(ctl);
         }
         if (ctl.degenerate) {                                                      // BVH.cpp:194 hit a BIG node: its permuted triangles go to both buffers
             crt_bvh_big_degenerate<<<chunks, T, 0, st>>>(bn, L.list[0], bigs[cur], chunkNode[cur], src, dst);

@@ -32,6 +32,9 @@
 #include "../../include/crt_types.h"
 
 #define CRT_LEAF_BIT 0x80000000u
+// CRT_KERNEL=ldstop only: an INNER reference with this bit names record (ref & 0xFFFF) of the tree-top table (crt_ldstop.h) instead of
+// a pair index; such references exist only inside that table and in CrtDevInstance::r2.w, which no other kernel form reads
+#define CRT_TOP_BIT 0x40000000u
 #define CRT_BLOCK 64      // one wave64 per workgroup: a finished wave frees its LDS and wave slot at once
 #ifndef CRT_WAVES_PER_SIMD
 #define CRT_WAVES_PER_SIMD 8   // 32 waves per CU: 64 VGPRs (the trace kernel fits them without scratch) and 5 KiB of LDS each = the CU's 160 KiB
@@ -50,6 +53,10 @@
 // 5.9 -> 6.6 (no SLP, 6 waves) -> 7.0 (7 waves) -> 7.6 Gray/s (8 waves) on multi-1M with frames in flight.)
 // (Explicit LDS pointer type: through a generic pointer the compiler read the stack with flat_load.)
 typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
+// loads through a constant-address-space pointer become scalar loads (s_load_*, scalar cache) when the address is wave-uniform
+typedef float crt_f32x4 __attribute__((ext_vector_type(4)));
+typedef const crt_f32x4 __attribute__((address_space(4)))* crt_const_f32x4_ptr;
+typedef const crt_f32x4 __attribute__((address_space(3)))* crt_lds_f32x4_ptr;
 #ifndef CRT_LDS_SLOTS
 #define CRT_LDS_SLOTS 20
 #endif
@@ -62,6 +69,7 @@ typedef uint32_t __attribute__((address_space(3))) * crt_lds_u32_ptr;
 #define CRT_OVF_WORDS_PER_BLOCK ((size_t)CRT_OVF_SLOTS_MAX * CRT_BLOCK)
 template <int PARK>
 struct CrtStackT {
+    static constexpr bool kTop = false;      // no LDS-resident tree tops (crt_ldstop.h's stack type says true)
     static constexpr int kLds = CRT_LDS_SLOTS - PARK;
     static_assert(PARK >= 0 && PARK <= CRT_MAX_PARK && kLds >= 1 && kLds <= CRT_STACK_DEPTH, "LDS slots");
     crt_lds_u32_ptr lds;     // this lane's slot 0
@@ -91,6 +99,7 @@ struct CrtStackT {
         return *overflow_slot(s - kLds);
     }
     // parked value k (0 <= k < PARK) of this lane
+    __device__ __forceinline__ crt_lds_f32x4_ptr top_record(uint32_t) const { return nullptr; }   // kTop stacks only (dead code here)
     __device__ __forceinline__ void park(int k, uint32_t v) const { lds[(kLds + k) * 64] = v; }
     __device__ __forceinline__ uint32_t parked(int k) const { return lds[(kLds + k) * 64]; }
 };
@@ -133,6 +142,7 @@ struct CrtDevScene {
     uint32_t tlasNodes;                      // 0: no tree (few instances, or none cullable)
     const uint32_t* __restrict__ alwaysList; // instances that are never culled (single-leaf meshes, unbounded), ascending
     uint32_t numAlways;
+    const float4* __restrict__ topPairs;     // CRT_KERNEL=ldstop: the top levels of every mesh's tree, CRT_TOP_PAIRS records (crt_ldstop.h); else unused
 };
 
 struct CrtFrame {
@@ -190,9 +200,6 @@ __device__ __forceinline__ float h2f(uint32_t bits16) { return __half2float(__us
 
 struct CrtDevInstance;
 struct Triout { float t, u, v; uint32_t tri; };
-// loads through a constant-address-space pointer become scalar loads (s_load_*, scalar cache) when the address is wave-uniform
-typedef float crt_f32x4 __attribute__((ext_vector_type(4)));
-typedef const crt_f32x4 __attribute__((address_space(4)))* crt_const_f32x4_ptr;
 
 struct LaneCounters {
     uint32_t rays, primary, secondary, hits, misses;
@@ -356,6 +363,8 @@ struct Traversal {
         }
     }
     // kernel_main.cl:200-210: transform the ray into instance `inst` and start at its root (record fetch: load_instance above)
+    // TOP (crt_ldstop.h): start at the root's record in the tree-top table (CrtDevInstance::r2.w) instead of the global pair
+    template <bool TOP = false>
     __device__ __forceinline__ void enter(const CrtDevScene& S, uint32_t inst, v3 o, v3 d, float bestSoFar, LaneCounters& lc)
     {
         curInst = inst;
@@ -364,7 +373,7 @@ struct Traversal {
         md = xform_xyz(I, d.x, d.y, d.z, 0.0f);
         inv = mk3(1.0f / md.x, 1.0f / md.y, 1.0f / md.z);       // native_recip pinned to IEEE
         tr.t = bestSoFar; tr.tri = 0; tr.u = 0.0f; tr.v = 0.0f;
-        ref = __float_as_uint(I.r0.w);                           // the root is popped at once: sp 1 -> 0, protection 0 -> 1
+        ref = __float_as_uint(TOP ? I.r2.w : I.r0.w);            // the root is popped at once: sp 1 -> 0, protection 0 -> 1
         sp = 0; prot = 1; inters = 0; active = true;
         if (COUNT) { lc.traversals++; lc.pops++; }
     }
@@ -384,13 +393,28 @@ struct Traversal {
         uint32_t nearRef, farRef;
         const uint32_t ref0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
         if (__ballot(ref != ref0) == 0) {
-            const crt_const_f32x4_ptr q = (crt_const_f32x4_ptr)(S.pairs + (size_t)ref0 * 4);
+            // (STK::kTop: a wave-uniform step on a tree-top record reads the table's GLOBAL copy through the scalar cache, as before)
+            const crt_const_f32x4_ptr q = (STK::kTop && (ref0 & CRT_TOP_BIT)) ? (crt_const_f32x4_ptr)(S.topPairs + (size_t)(ref0 & 0xFFFFu) * 4)
+                                                                             : (crt_const_f32x4_ptr)(S.pairs + (size_t)ref0 * 4);
+            const crt_f32x4 a = q[0], b = q[1], c4 = q[2], e = q[3];
+            dist1 = intersect_aabb(mo, inv, make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), tr.t);
+            dist2 = intersect_aabb(mo, inv, make_float4(c4.x, c4.y, c4.z, c4.w), make_float4(e.x, e.y, e.z, e.w), tr.t);
+            nearRef = __float_as_uint(a.w); farRef = __float_as_uint(c4.w);
+#ifndef CRT_TOP_NO_LDS_PATH
+#define CRT_TOP_NO_LDS_PATH 0                // A/B builds: 1 = the four-wave form without its LDS reads (what the workgroup shape alone costs)
+#endif
+        } else if (STK::kTop && !CRT_TOP_NO_LDS_PATH && __ballot(!(ref & CRT_TOP_BIT)) == 0) {
+            // crt_ldstop.h: EVERY lane of this step wants a record of the LDS-resident tree tops, and they differ: four ds_read_b128 per
+            // lane instead of four vector-memory instructions for the wave (north_star's "hot BVH tiles staged in LDS")
+            const auto q = stack.top_record(ref & 0xFFFFu);
             const crt_f32x4 a = q[0], b = q[1], c4 = q[2], e = q[3];
             dist1 = intersect_aabb(mo, inv, make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), tr.t);
             dist2 = intersect_aabb(mo, inv, make_float4(c4.x, c4.y, c4.z, c4.w), make_float4(e.x, e.y, e.z, e.w), tr.t);
             nearRef = __float_as_uint(a.w); farRef = __float_as_uint(c4.w);
         } else {
-            const float4* p = S.pairs + (size_t)ref * 4;        // one aligned 64-byte record
+            // one aligned 64-byte record (a step that mixes tree-top and other records takes the top ones from the table's global copy:
+            // the four vector loads are issued for the wave either way)
+            const float4* p = (STK::kTop && (ref & CRT_TOP_BIT)) ? S.topPairs + (size_t)(ref & 0xFFFFu) * 4 : S.pairs + (size_t)ref * 4;
             const float4 lmin = p[0], lmax = p[1], rmin = p[2], rmax = p[3];
             dist1 = intersect_aabb(mo, inv, lmin, lmax, tr.t);
             dist2 = intersect_aabb(mo, inv, rmin, rmax, tr.t);
@@ -610,7 +634,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
     c.hit.t = 0.0f; c.hit.u = 0.0f; c.hit.v = 0.0f; c.hit.tri = 0;
     Traversal<COUNT> T; T.reset();
 
-    if (TLAS) {
+    if constexpr (TLAS) {
         // Many instances: every lane collects its (few) candidates from the instance tree and walks them in ascending
         // order -- the same instances, in the same order, as the chunked loop below would. A wave in which some lane
         // has more than CRT_TLAS_LIST candidates takes the chunked loop instead.
@@ -634,7 +658,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
                     } else {
                         if (COUNT && ANYHIT) { const uint32_t n = k - (uint32_t)(prev + 1); lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; }
                         prev = (int)k;
-                        T.enter(S, k, o, d, c.distance, lc);
+                        T.template enter<STK::kTop>(S, k, o, d, c.distance, lc);
                     }
                 }
                 trip_steps<COUNT, false, ANYHIT>(S, stack, T, c, lc, done);
@@ -670,7 +694,7 @@ __device__ __forceinline__ Closest closest_hit(const CrtDevScene& S, v3 o, v3 d,
                         const uint32_t n = (uint32_t)__popcll(below);
                         lc.traversals += n; lc.pops += n; lc.innerVisits += n; lc.culled += n; culledLeft &= ~below;
                     }
-                    T.enter(S, base + k, o, d, c.distance, lc);
+                    T.template enter<STK::kTop>(S, base + k, o, d, c.distance, lc);
                 }
             }
             trip_steps<COUNT, ITERS, ANYHIT>(S, stack, T, c, lc, done);

@@ -122,6 +122,7 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
     // crt_debug_last_kernel: the Trace launch(es) of this frame under the names rocprofv3 prints for them
     if (refill) snprintf(g.lastKernel, sizeof g.lastKernel, "%s<%d,%d>", g.refill == 2 ? "crt_trace_block_kernel" : "crt_trace_refill_kernel", stamped ? 0 : (int)count, (int)stamped);
     else if (g.wavefront) snprintf(g.lastKernel, sizeof g.lastKernel, "crt_primary_kernel<%d>+crt_wavefront_scan_kernel+crt_bounce_kernel<%d>", (int)count, (int)count);
+    else if (g.ldstop) snprintf(g.lastKernel, sizeof g.lastKernel, "crt_trace_ldstop_kernel<%d>", (int)count);
     if (count) HIPCHK(hipMemsetAsync(g.counters, 0, CRT_NUM_COUNTERS * sizeof(unsigned long long), fs.stream));
     if (flags & CRT_RENDER_STAMPS) {                      // diagnostic launch with per-wave stamps
         const size_t need = (16 + (size_t)grid * 8) * sizeof(unsigned long long);
@@ -144,6 +145,11 @@ static int launch_trace(const CrtDevScene& S, const CrtFrame& F, int flags, unsi
             else crt_trace_block_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters, fs.blockQueue);
         } else if (count) crt_trace_refill_kernel<true><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters);
         else crt_trace_refill_kernel<false><<<grid, CRT_BLOCK, 0, fs.stream>>>(S, F, out, g.counters);
+    } else if (g.ldstop) {                                 // four tiles per workgroup sharing an LDS copy of the tree tops (crt_ldstop.h)
+        *epilogueApplied = true;
+        const unsigned gridW = (unsigned)((F.slotsPerXcd + CRT_TOP_WAVES - 1) / CRT_TOP_WAVES) * 8u;
+        if (count) crt_trace_ldstop_kernel<true><<<gridW, CRT_BLOCK * CRT_TOP_WAVES, 0, fs.stream>>>(S, F, out, g.counters);
+        else crt_trace_ldstop_kernel<false><<<gridW, CRT_BLOCK * CRT_TOP_WAVES, 0, fs.stream>>>(S, F, out, g.counters);
     } else if (g.wavefront) {                              // bounce 0, ballot compaction, bounce 1
         // per-slot state (crt1_render sized it): queue = one 64-record range per primary wave; counts, offsets, per-XCD totals
         uint32_t* cnt = fs.wfCount; uint32_t* offs = cnt + grid; uint32_t* total = offs + grid;
@@ -249,14 +255,14 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     // the frame slot, so it keeps frames in flight like the default kernel.)
     const bool variant = g.wavefront != 0;
     if ((flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION)) && (flags & CRT_RENDER_STAMPS)) return CRT_E_UNSUPPORTED;   // the stamped instantiation is the plain one
-    // ONE rule for the opt-in kernel forms (CRT_KERNEL=wavefront / refill / block; VERDICT r5 #1b): a frame the selected form cannot
+    // ONE rule for the opt-in kernel forms (CRT_KERNEL=wavefront / refill / block / ldstop; VERDICT r5 #1b): a frame the selected form cannot
     // render is refused with CRT_E_UNSUPPORTED -- never rendered by another kernel behind the caller's back. What they lack: shadow rays,
-    // refraction, the three-frame diagnostic mix, the instance tree (CRT_TLAS=1); wavefront: the stamped launch; refill / block: more than
+    // refraction, the three-frame diagnostic mix, the instance tree (CRT_TLAS=1); wavefront / ldstop: the stamped launch; refill / block: more than
     // 64 instances (one 64-bit candidate mask per lane).
-    if (variant || g.refill) {
+    if (variant || g.refill || g.ldstop) {
         if (flags & (CRT_RENDER_SHADOWS | CRT_RENDER_REFRACTION | CRT_RENDER_DIAG_MIX3)) return CRT_E_UNSUPPORTED;
         if (g.forceTlas == 1) return CRT_E_UNSUPPORTED;
-        if (variant && (flags & CRT_RENDER_STAMPS)) return CRT_E_UNSUPPORTED;
+        if ((variant || g.ldstop) && (flags & CRT_RENDER_STAMPS)) return CRT_E_UNSUPPORTED;
         if (g.refill && args->numMeshes > 64u) return CRT_E_UNSUPPORTED;
     }
     const bool refill = g.refill != 0;
@@ -310,7 +316,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
         F.order = fs.mixOrder; F.listLen = fs.mixLen; F.listCap = S3; F.cost = nullptr;
         grid = 8u * (unsigned)S3;
     } else
-    if (g.feedback && !g.wavefront && !refill && (!pipelined || g.feedbackAsync)) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
+    if (g.feedback && !g.wavefront && !g.ldstop && !refill && (!pipelined || g.feedbackAsync)) { rc = prepare_launch_lists(F, grid, fs, pipelined); if (rc) return rc; }
     // CRT_KERNEL=refill: the Trace launch (and its feedback lists) count BLOCKS of CRT_REFILL_TILES tiles where F counts tiles
     CrtFrame FB = F; unsigned gridB = grid;
     if (refill) {
@@ -346,6 +352,7 @@ int crt1_render(const CrtTraceArgs* args, const float invView[16], const float i
     }
     {   // overflow blocks: one per workgroup of the largest launch of this frame
         size_t blocks = grid;
+        if (g.ldstop) blocks = (size_t)((F.slotsPerXcd + CRT_TOP_WAVES - 1) / CRT_TOP_WAVES) * CRT_TOP_WAVES * 8;   // one block per WAVE of the four-wave workgroups
         rc = ensure_overflow(fs, blocks); if (rc) return rc;
     }
     fill_scene(S, args->numMeshes, fs, beyond_cull_range(sqrt((double)args->cameraPos[0] * args->cameraPos[0] + (double)args->cameraPos[1] * args->cameraPos[1] + (double)args->cameraPos[2] * args->cameraPos[2])));

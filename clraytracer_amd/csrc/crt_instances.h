@@ -16,6 +16,12 @@ int rebuild_bvh_layout()
     }
     crt_make_root_refs<<<(CRT_MAX_MESHES + 255) / 256, 256, 0, g.stream>>>(g.rawNodes, g.nodeCount, (uint32_t)g.triCap, g.roots, g.numRoots, g.rootRefs, g.bigLeaf, g.err);
     HIPCHK(hipGetLastError());
+    {   // the tree-top table of CRT_KERNEL=ldstop (crt_ldstop.h): the records split evenly over the meshes that have a root. Built for every
+        // session (one 128-thread launch per BVH upload); only the ldstop kernel reads it and the references into it (CrtDevInstance::r2.w)
+        const uint32_t perMesh = g.numRoots ? (uint32_t)CRT_TOP_PAIRS / g.numRoots : 0u;
+        crt_build_top_kernel<<<1, CRT_MAX_MESHES, 0, g.stream>>>(g.pairs, g.rootRefs, g.numRoots, perMesh, g.topPairs, g.topRootRefs);
+        HIPCHK(hipGetLastError());
+    }
     int err = 0;
     HIPCHK(hipMemcpyAsync(&err, g.err, sizeof(int), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -219,7 +225,7 @@ int ensure_slot_instances(FrameSlot& fs)
     if (g.hTlasNodes) HIPCHK(hipMemcpyAsync(fs.tlas, fs.staging + kStageTlas, g.hTlasNodes * sizeof(CrtTlasNode), hipMemcpyHostToDevice, fs.stream));
     if (g.hNumAlways) HIPCHK(hipMemcpyAsync(fs.alwaysList, fs.staging + kStageAlways, g.hNumAlways * sizeof(uint32_t), hipMemcpyHostToDevice, fs.stream));
     HIPCHK(hipEventRecord(fs.staged, fs.stream));
-    crt_relayout_instances<<<(CRT_MAX_INSTANCES + 255) / 256, 256, 0, fs.stream>>>(fs.instances, g.rootRefs, CRT_MAX_INSTANCES, fs.devInstances);
+    crt_relayout_instances<<<(CRT_MAX_INSTANCES + 255) / 256, 256, 0, fs.stream>>>(fs.instances, g.rootRefs, g.topRootRefs, CRT_MAX_INSTANCES, fs.devInstances);
     HIPCHK(hipGetLastError());
     fs.tlasNodes = g.hTlasNodes; fs.numAlways = g.hNumAlways; fs.instVersion = g.instVersion;
     return CRT_OK;

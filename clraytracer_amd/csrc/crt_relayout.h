@@ -67,7 +67,8 @@ __global__ void crt_make_root_refs(const CrtBVHNode* __restrict__ raw, uint32_t 
     rootRefs[k] = make_ref(raw[r], r, nodeCount, triCap, bigLeaf, err);
 }
 
-__global__ void crt_relayout_instances(const CrtMeshInstance* __restrict__ raw, const uint32_t* __restrict__ rootRefs,
+// (r2.w: the mesh's root as a reference into the tree-top table, or the same global reference as r0.w -- read by CRT_KERNEL=ldstop only)
+__global__ void crt_relayout_instances(const CrtMeshInstance* __restrict__ raw, const uint32_t* __restrict__ rootRefs, const uint32_t* __restrict__ topRootRefs,
                                        uint32_t count, CrtDevInstance* __restrict__ out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +78,7 @@ __global__ void crt_relayout_instances(const CrtMeshInstance* __restrict__ raw, 
     CrtDevInstance d;
     d.r0 = make_float4(m.inverseTransform.m[0][0], m.inverseTransform.m[0][1], m.inverseTransform.m[0][2], __uint_as_float(rootRefs[mesh]));
     d.r1 = make_float4(m.inverseTransform.m[1][0], m.inverseTransform.m[1][1], m.inverseTransform.m[1][2], __uint_as_float((uint32_t)m.materialStart));
-    d.r2 = make_float4(m.inverseTransform.m[2][0], m.inverseTransform.m[2][1], m.inverseTransform.m[2][2], 0.0f);
+    d.r2 = make_float4(m.inverseTransform.m[2][0], m.inverseTransform.m[2][1], m.inverseTransform.m[2][2], __uint_as_float(topRootRefs[mesh]));
     d.r3 = make_float4(m.inverseTransform.m[3][0], m.inverseTransform.m[3][1], m.inverseTransform.m[3][2], 0.0f);
     out[i] = d;
 }

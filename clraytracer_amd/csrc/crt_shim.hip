@@ -4,7 +4,7 @@
 // uploads, the per-frame RayGen -> Trace -> PostProcess launch (Renderer.cpp:305-375). Uploads
 // arrive in the reference's struct layouts and are re-laid-out on the device (crt_device.h).
 // One translation unit; the parts (round 5 split what used to be one 2,000-line file):
-//   kernels     crt_device.h (traversal + shading), crt_kernels.h (launches), crt_refill.h (opt-in in-wave compaction forms),
+//   kernels     crt_device.h (traversal + shading), crt_kernels.h (launches), crt_refill.h (opt-in in-wave compaction forms), crt_ldstop.h (opt-in: tree tops staged in LDS),
 //               crt_relayout.h (upload-time layouts), crt_bvh_build.h (device BuildBVH)
 //   host state  crt_state.h (State / FrameSlot, helpers), crt_instances.h (instance tables, cull bounds, instance tree)
 //   entry impl  crt_upload.h (init, uploads, read-backs), crt_bvh_driver.h (crt_build_bvh), crt_frame.h (crt_render and what a frame
@@ -19,6 +19,7 @@
 #include "../../include/crt_debug.h"
 #include "crt_kernels.h"
 #include "crt_refill.h"
+#include "crt_ldstop.h"
 #include "crt_relayout.h"
 #include "crt_bvh_build.h"
 #include <vector>

@@ -99,10 +99,13 @@ struct State {
     float lastView[35] = { 0 }; unsigned long long lastViewInst = 0; bool viewMoved = false;   // camera matrices + position / instance version of the last sorted frame
     float splitBeta = CRT_SPLIT_BETA, splitBetaAsync = CRT_SPLIT_BETA_ASYNC;   // split a tile whose wave would run longer than beta x the XCD's time for the frame
     int refill = 0;                            // CRT_KERNEL=refill / block: 1 = in-tile lane refill, 2 = phase-separated block compaction (crt_refill.h), every frame (one they cannot render is refused)
+    int ldstop = 0;                            // CRT_KERNEL=ldstop: four-wave workgroups sharing an LDS copy of the tree tops (crt_ldstop.h)
+    float4* topPairs = nullptr; uint32_t* topRootRefs = nullptr;   // the tree-top table (CRT_TOP_PAIRS records) and every mesh's entry into it, rebuilt with the BVH layout
     int wavefront = 0;                         // CRT_KERNEL=wavefront: one launch per bounce, ordered ballot compaction in between (crt_kernels.h)
     char lastKernel[128] = { 0 };              // crt_debug_last_kernel: the Trace launch(es) of the most recently submitted frame
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
+    std::vector<CrtBuildCtl> buildReplay; unsigned long long buildReplayKey = 0;   // CRT_DEBUG_BVH_REPLAY (crt_bvh_driver.h): the level records of the last build
     bool buildNoSpin = false;                                   // the spin on buildCtlHost timed out once: synchronise the stream per level instead
     CrtBuildCtlHost* buildCtlHost = nullptr; uint32_t buildSeq = 0;   // pinned: the per-level control record the builder publishes (crt_bvh_publish)
     CrtTri* buildTris = nullptr;                               // crt_build_bvh: second triangle pool (same indexing as rawTris)
@@ -196,6 +199,7 @@ void fill_scene(CrtDevScene& S, uint32_t numInstances, const FrameSlot& fs, bool
     if (S.numTexels < 1) S.numTexels = 1;
     S.numInstances = numInstances;
     S.tlas = fs.tlas; S.tlasNodes = fs.tlasNodes; S.alwaysList = fs.alwaysList; S.numAlways = fs.numAlways;
+    S.topPairs = g.topPairs;
     if (noCull) { S.instBounds = g.noCullBounds; S.tlas = nullptr; S.tlasNodes = 0; S.alwaysList = nullptr; S.numAlways = 0; g.noCullFrames++; }
 }
 // true when a ray origin this far from the world origin is outside the proven range (NaN counts as outside)

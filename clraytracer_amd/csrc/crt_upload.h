@@ -58,6 +58,9 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.bigLeaf, (g.triCap + 1) * sizeof(uint32_t)));
     HIPCHK(hipMemset(g.bigLeaf + g.triCap, 0, sizeof(uint32_t)));      // crt_empty_ref: a leaf of zero triangles
     HIPCHK(hipMalloc(&g.rootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.topRootRefs, CRT_MAX_MESHES * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g.topPairs, CRT_TOP_PAIRS * 4 * sizeof(float4)));
+    HIPCHK(hipMemset(g.topPairs, 0, CRT_TOP_PAIRS * 4 * sizeof(float4)));
     HIPCHK(hipMalloc(&g.texels, (g.texelByteCap / 3 + 2) * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.materials, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
@@ -71,15 +74,16 @@ static int init_impl(int device, int width, int height)
     }
     g.numCUs = prop.multiProcessorCount;
     {   // CRT_KERNEL: the Trace kernel structure of this session. Unset / "" / "default": the megakernel (faster);
-        // "wavefront", "refill", "block": the opt-in compaction forms. Anything else is a typo, not a wish for
+        // "wavefront", "refill", "block": the opt-in compaction forms, "ldstop": tree tops staged in LDS. Anything else is a typo, not a wish for
         // the default: the session refuses to start (VERDICT r5 #3 -- a variant test must not pass because the name stopped matching).
         const char* e = getenv("CRT_KERNEL");
-        g.wavefront = 0; g.refill = 0;
+        g.wavefront = 0; g.refill = 0; g.ldstop = 0;
         if (e && *e && strcmp(e, "default") != 0) {
             if (strcmp(e, "wavefront") == 0) g.wavefront = 1;
+            else if (strcmp(e, "ldstop") == 0) g.ldstop = 1;
             else if (strcmp(e, "refill") == 0) g.refill = 1;
             else if (strcmp(e, "block") == 0) g.refill = 2;
-            else { fprintf(stderr, "crt_init: CRT_KERNEL=%s is not one of default, wavefront, refill, block\n", e); return CRT_E_BAD_ARGUMENT; }
+            else { fprintf(stderr, "crt_init: CRT_KERNEL=%s is not one of default, wavefront, refill, block, ldstop\n", e); return CRT_E_BAD_ARGUMENT; }
         }
     }
     { const char* e = getenv("CRT_SPLIT_BETA"); g.splitBeta = e ? (float)atof(e) : CRT_SPLIT_BETA; }
@@ -94,7 +98,8 @@ static int init_impl(int device, int width, int height)
     { const char* e = getenv("CRT_FEEDBACK"); g.feedback = !(e && atoi(e) == 0); }
     { const char* e = getenv("CRT_FEEDBACK_ASYNC"); g.feedbackAsync = (e && atoi(e) != 0); }
     HIPCHK(hipMemset(g.roots, 0, CRT_MAX_MESHES * sizeof(uint32_t)));
-    { std::vector<uint32_t> e(CRT_MAX_MESHES, crt_empty_ref((uint32_t)g.triCap)); HIPCHK(hipMemcpy(g.rootRefs, e.data(), e.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); }
+    { std::vector<uint32_t> e(CRT_MAX_MESHES, crt_empty_ref((uint32_t)g.triCap)); HIPCHK(hipMemcpy(g.rootRefs, e.data(), e.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(g.topRootRefs, e.data(), e.size() * sizeof(uint32_t), hipMemcpyHostToDevice)); }
     HIPCHK(hipMemset(g.materials, 0, CRT_MAX_MATERIALS * sizeof(CrtMaterial)));
     HIPCHK(hipMemset(g.textures, 0, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMemset(g.texels, 0, 64));
@@ -116,7 +121,7 @@ static void release_all()
 {
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.materials, g.textures, g.rays, g.counters, g.err,
+                     g.texels, g.materials, g.textures, g.rays, g.counters, g.err, g.topPairs, g.topRootRefs,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.noCullBounds };
     for (FrameSlot& fs : g.slot) {
         void* q[] = { fs.out, fs.aux, fs.blockQueue, fs.wfCount, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };

@@ -56,11 +56,12 @@ def caterpillar(levels, reverse=False):
     return tris, nodes
 
 
-@pytest.fixture(params=["megakernel", "wavefront"])
+@pytest.fixture(params=["megakernel", "wavefront", "ldstop"])
 def structure(request, monkeypatch):
-    """CRT_KERNEL (read by crt_init): the default megakernel or the one-launch-per-bounce form; both share CrtStack."""
-    if request.param == "wavefront":
-        monkeypatch.setenv("CRT_KERNEL", "wavefront")
+    """CRT_KERNEL (read by crt_init): the default megakernel or the one-launch-per-bounce form, which share CrtStack (20 LDS slots), and the
+    four-wave form with the tree tops in LDS, whose waves keep 15 slots in LDS and index the overflow area by wave (CrtStackTop)."""
+    if request.param != "megakernel":
+        monkeypatch.setenv("CRT_KERNEL", request.param)
     else:
         monkeypatch.delenv("CRT_KERNEL", raising=False)
     return request.param
@@ -92,7 +93,7 @@ def test_hand_built_deep_tree_matches_oracle(levels, reverse, structure, nthread
         args.time, args.numMeshes, args.sunAngle = 0.0, 1, float(sc.sun_angle)
         fp = C.POINTER(C.c_float)
         ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle)
-        for flags in ((8, 0, 4, 4) if structure == "wavefront" else (8, 0, 4, 4, 8 | 32)):   # shadow rays: default kernel only
+        for flags in ((8, 0, 4, 4) if structure != "megakernel" else (8, 0, 4, 4, 8 | 32)):   # shadow rays: default kernel only
             assert hip.crt_render(C.byref(args), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), flags) == 0
             if flags & 32:
                 ref, st = orc.trace(orc.raygen(W, H, iv, ip), pos, sc.sun_angle, shadows=True)

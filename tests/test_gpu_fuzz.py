@@ -85,7 +85,8 @@ def lattice_views(rng, count=4):
     return views
 
 
-FORMS = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<"}
+FORMS = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<",
+         "ldstop": "crt_trace_ldstop_kernel<"}
 
 
 @pytest.fixture(params=list(FORMS))

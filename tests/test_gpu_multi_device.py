@@ -246,7 +246,7 @@ def test_synchronous_frame_overlaps_the_devices_shares():
     assert two < 1.6 * one, (one, two)
 
 
-@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block", "ldstop"])
 def test_compaction_kernels_behind_several_device_states(monkeypatch, variant):
     """The opt-in kernel structures (round 5: the wavefront form keeps frames in flight with a per-slot queue; refill / block count blocks
     where the default kernel counts tiles) also run one share of a banded frame each: three device states, uneven bands, synchronous
@@ -258,7 +258,7 @@ def test_compaction_kernels_behind_several_device_states(monkeypatch, variant):
     monkeypatch.setenv("CRT_KERNEL", variant)
     with driver.Session(w, h, devices=[0, 0, 0]) as s:
         s.load_scene(sc)
-        prefix = {"wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<"}[variant]
+        prefix = {"wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<", "ldstop": "crt_trace_ldstop_kernel<"}[variant]
         s.render_raw(8)
         assert s.last_kernel().startswith(prefix), s.last_kernel()
         assert np.array_equal(bits(s.read_output()), bits(ref)) and s.counters() == ref_cnt

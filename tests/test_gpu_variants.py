@@ -8,10 +8,11 @@ from util import bits
 pytestmark = pytest.mark.gpu
 FLAG_COUNT = 8
 # what crt_debug_last_kernel must report for a frame of each form (the names rocprofv3 prints, profiles/r0N{wavefront,refill,block}_summary.md)
-KERNEL_OF = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<"}
+KERNEL_OF = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<",
+             "ldstop": "crt_trace_ldstop_kernel<"}
 
 
-@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block", "ldstop"])
 def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     """The opt-in kernel structure (CRT_KERNEL=wavefront: one launch per bounce with ballot compaction in between) renders
     the same bits and counts the same work as the default megakernel. (Round 1's `persistent` and `lds` structures were
@@ -48,7 +49,7 @@ def test_kernel_variants_are_bit_identical(nthreads, monkeypatch, variant):
     assert not np.array_equal(bits(fused[0]), bits(ref)) and not np.array_equal(bits(fused[2]), bits(fused[0]))
 
 
-@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block", "ldstop"])
 def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkeypatch, variant):
     """BASELINE config 4 as written ("LDS stack + wavefront compaction on"): multi-1M, 1920x1080, rendered by the wavefront form
     (crt_primary_kernel -> ballot compaction -> crt_bounce_kernel; the bounce loop of kernel_main.cl:187 split into launches)
@@ -80,7 +81,7 @@ def test_wavefront_compaction_at_config4_size_equals_the_oracle(nthreads, monkey
         print(f"{variant} multi-1M 1920x1080: {st['rays']} rays, {st['secondary']} compacted bounce rays, frame and counters equal to the oracle")
 
 
-@pytest.mark.parametrize("variant", ["wavefront", "refill", "block"])
+@pytest.mark.parametrize("variant", ["wavefront", "refill", "block", "ldstop"])
 def test_a_form_refuses_what_it_cannot_render(monkeypatch, variant):
     """ONE rule (VERDICT r5 #1b): a frame the selected form cannot render -- shadow rays, refraction, the diagnostic mix, the stamped
     launch (wavefront), more than 64 instances (refill / block), a forced instance tree -- returns CRT_E_UNSUPPORTED (-5) and renders
@@ -97,12 +98,12 @@ def test_a_form_refuses_what_it_cannot_render(monkeypatch, variant):
         assert name.startswith(KERNEL_OF[variant])
         a, iv, ip = s.trace_args()
         fp = C.POINTER(C.c_float)
-        refused = [SHADOWS, REFRACT, SHADOWS | REFRACT, SHADOWS | POST, SHADOWS | 4, MIX3] + ([STAMPS] if variant == "wavefront" else [])
+        refused = [SHADOWS, REFRACT, SHADOWS | REFRACT, SHADOWS | POST, SHADOWS | 4, MIX3] + ([STAMPS] if variant in ("wavefront", "ldstop") else [])
         for f in refused:
             assert s.hip.crt_render(C.byref(a), iv.ctypes.data_as(fp), ip.ctypes.data_as(fp), f) == _lib.CRT_E_UNSUPPORTED, f
             assert s.last_kernel() == name
         assert np.array_equal(bits(s.read_output()), bits(frame))
-        if variant != "wavefront":
+        if variant in ("refill", "block"):
             s.render_raw(STAMPS)                                            # refill / block have stamped instantiations of their own
             assert s.last_kernel().startswith(KERNEL_OF[variant]) and np.array_equal(bits(s.read_output()), bits(frame))
             a.numMeshes = 65                                                # one 64-bit candidate mask per lane
@@ -112,6 +113,40 @@ def test_a_form_refuses_what_it_cannot_render(monkeypatch, variant):
         s.load_scene(sc)
         a, iv, ip = s.trace_args()
         assert s.hip.crt_render(C.byref(a), iv.ctypes.data_as(C.POINTER(C.c_float)), ip.ctypes.data_as(C.POINTER(C.c_float)), 0) == _lib.CRT_E_UNSUPPORTED
+
+
+def test_ldstop_tree_top_table_on_one_and_on_many_meshes(nthreads, monkeypatch):
+    """CRT_KERNEL=ldstop (north_star's "hot BVH tiles staged in LDS", crt_ldstop.h): the 252-record table is split over the scene's meshes --
+    one mesh gets 7-8 levels of its tree (cornell-1k), two meshes 126 records each (tiny), and with more instances than one candidate mask holds
+    (130, the chunked linear loop) the form still renders the default kernel's frame and counts the default kernel's work."""
+    for name, extra in (("cornell-1k", 0), ("tiny", 0), ("tiny", 128)):
+        sc = scenes.get(name)
+        frames = {}
+        for form in ("default", "ldstop"):
+            monkeypatch.setenv("CRT_KERNEL", form)
+            with driver.Session(320, 200, device=0) as s:
+                s.load_scene(sc)
+                if extra:
+                    s.h.crth_begin_instances()
+                    for k in range(len(sc.instances) + extra):
+                        m = scenes._trs(0.5 + 0.1 * (k % 4), (0.2, 1.0, 0.3), 0.41 * k, (float((k % 13) - 6) * 5.0, float((k // 13) - 5) * 5.0, -float(k % 5) * 3.0))
+                        pm, keep = _lib_fptr(m)
+                        s.h.crth_register_instance(k % 2, 0xFFFF, pm)
+                    s.h.crth_end_instances()
+                    s.set_camera((0.0, 0.0, 60.0), scenes._normalize((0.0, 0.0, -1.0)))
+                s.render_raw(FLAG_COUNT)
+                assert s.last_kernel().startswith(KERNEL_OF[form])
+                frames[form] = (s.read_output().copy(), s.counters())
+                for _ in range(4):
+                    s.render_raw(4)
+                assert np.array_equal(bits(s.read_output()), bits(frames[form][0]))
+        assert np.array_equal(bits(frames["ldstop"][0]), bits(frames["default"][0])), (name, extra)
+        assert frames["ldstop"][1] == frames["default"][1] and frames["default"][1]["hits"] > 0, (name, extra)
+
+
+def _lib_fptr(m):
+    from clraytracer_amd import _lib
+    return _lib.fptr(m)
 
 
 def test_unknown_kernel_name_fails_init(monkeypatch):

@@ -21,7 +21,7 @@ W, H = 1920, 1080
 SCENES = [("cornell-1k", 4.0), ("sponza-class-250k", 45.0), ("multi-1M", 14.0), ("multi-1M-dense", 14.0), ("sponza-sibenik", 20.0), ("nanosuit-demo", 12.0)]
 threads = min(64, len(os.sched_getaffinity(0)))
 form = os.environ.get("CRT_KERNEL") or "default"
-prefix = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<"}[form]
+prefix = {"default": "crt_trace_kernel<", "wavefront": "crt_primary_kernel<", "refill": "crt_trace_refill_kernel<", "block": "crt_trace_block_kernel<", "ldstop": "crt_trace_ldstop_kernel<"}[form]
 grand = {"frames": 0, "rays": 0, "pixels_differing": 0}
 t_all = time.time()
 for name, extent in SCENES:

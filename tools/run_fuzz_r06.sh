@@ -7,8 +7,8 @@ set -e -o pipefail
 out=gpurun_out
 : > $out/r06_fuzz.txt; : > $out/r06_random_views.txt
 { echo "# default kernel"; timeout -k 10 400 python tools/fuzz_many.py 100000 1500; } >> $out/r06_fuzz.txt 2>&1
-for k in wavefront refill block; do { echo "# CRT_KERNEL=$k"; CRT_KERNEL=$k timeout -k 10 300 python tools/fuzz_many.py 101000 600; } >> $out/r06_fuzz.txt 2>&1; done
+for k in wavefront refill block ldstop; do { echo "# CRT_KERNEL=$k"; CRT_KERNEL=$k timeout -k 10 300 python tools/fuzz_many.py 101000 600; } >> $out/r06_fuzz.txt 2>&1; done
 { echo "# default kernel"; timeout -k 10 300 python tools/random_views.py 30; } >> $out/r06_random_views.txt 2>&1
-for k in wavefront refill block; do { echo "# CRT_KERNEL=$k"; CRT_KERNEL=$k timeout -k 10 300 python tools/random_views.py 12; } >> $out/r06_random_views.txt 2>&1; done
+for k in wavefront refill block ldstop; do { echo "# CRT_KERNEL=$k"; CRT_KERNEL=$k timeout -k 10 300 python tools/random_views.py 12; } >> $out/r06_random_views.txt 2>&1; done
 grep -c Traceback $out/r06_fuzz.txt $out/r06_random_views.txt || true
 tail -2 $out/r06_fuzz.txt; tail -2 $out/r06_random_views.txt
