@@ -655,12 +655,17 @@ def main():
                         left = nb["leftFirst"][inner].astype(np.int64)
                         frontier = np.concatenate([left, left + 1]); depth += 1
                     moved = 320 * tri_levels
+                    lv_b, ln_b = C.c_uint32(0), C.c_uint32(0)
+                    hip.crt_debug_build_stats(C.byref(lv_b), C.byref(ln_b))
                     out["bvh_build"] = {"ms": round(best_b * 1e3, 3), "triangles": int(len(trisb)), "nodes": int(used_b.value), "levels": depth - 1,
+                                        "launches": int(ln_b.value), "level_handshakes": int(lv_b.value),
+                                        "one_submission_floor": "3.86 ms against 4.10 (profiles/r06_bvh_replay.txt: every launch enqueued back to back with recorded grid sizes, no publish kernel, "
+                                                                "no host wait per level): any device-driven level loop can gain at most 6 %",
                                         "bytes_moved": int(moved), "frac_of_hbm": round(moved / best_b / 1e9 / HBM_PEAK_GBS, 4),
                                         "triangles_per_s": round(len(trisb) / best_b, 0),
                                         "note": "crt_build_bvh incl. the re-layout for rendering, best of 3 (host wall clock around the call); bytes_moved = 320 B x the sum over all "
                                                 "nodes of their triangle count (three reads and one write of an 80-B Tri per open node and level): a lower bound; the build is "
-                                                "launch- and atomics-bound (~150 launches, one 16-B read-back per level), not bandwidth-bound"}
+                                                "launch- and atomics-bound (`launches`, one 16-B control record published per level), not bandwidth-bound"}
             except Exception as e:  # pragma: no cover - an extra, never the reason for a missing line
                 out["bvh_build"] = {"error": str(e)}
             # BASELINE config 4 as written ("LDS stack + wavefront compaction on"): the wavefront form of Trace -- bounce 0, ballot compaction of

@@ -21,6 +21,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         if (h && atoi(h) != 0 && f && atoi(f) != 0) return CRT_E_OUT_OF_RANGE;
     }
     RCCHK(sync_all());
+    g.buildLaunches = 0; g.buildLevels = 0;
 
     // second triangle pool (allocated on first use, indexed like rawTris) and scratch:
     // build nodes | rank, holes, backL | 2 x 3 id lists | 2 x BIG-node scratch | 2 x chunk->node + 3 per-chunk counts | mesh counts, roots | scalars
@@ -80,8 +81,8 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         }
         HIPCHK(hipStreamSynchronize(st));                                          // ids[] go out of scope
     }
-    crt_bvh_centroids<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(A, firstTri, total);
-    crt_bvh_init_roots<<<1, 1, 0, st>>>(bn, dCounts, numMeshes, (uint32_t)firstTri, bigs[0], chunkNode[0]);
+    crt_bvh_centroids<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(A, firstTri, total); ++g.buildLaunches;
+    crt_bvh_init_roots<<<1, 1, 0, st>>>(bn, dCounts, numMeshes, (uint32_t)firstTri, bigs[0], chunkNode[0]); ++g.buildLaunches;
     HIPCHK(hipGetLastError());
 
     // Measurement hook (CRT_DEBUG_HOOKS=1 + CRT_DEBUG_BVH_REPLAY=1): the builder is deterministic, so a build of the SAME input can
@@ -105,8 +106,8 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     const unsigned W = CRT_BVH_WAVES, T = CRT_BVH_BIG_THREADS;
     auto bounds = [&](int p, const uint32_t n[3], uint32_t nChunks, const CrtTri* tris) {
         const CrtBuildLists& L = lists[p];
-        if (n[0]) { crt_bvh_big_reset<<<(n[0] + 255) / 256, 256, 0, st>>>(bigs[p], n[0]);
-                    crt_bvh_big_bounds<<<nChunks, T, 0, st>>>(bn, L.list[0], bigs[p], chunkNode[p], tris); }
+        if (n[0]) { crt_bvh_big_reset<<<(n[0] + 255) / 256, 256, 0, st>>>(bigs[p], n[0]); ++g.buildLaunches;
+                    crt_bvh_big_bounds<<<nChunks, T, 0, st>>>(bn, L.list[0], bigs[p], chunkNode[p], tris); ++g.buildLaunches; }
         // (MID and TINY nodes compute their bounds at the top of crt_bvh_mid / crt_bvh_tiny: round 5, 26 launches fewer per 1 M-triangle build)
     };
     bounds(0, cnt, chunks, A);
@@ -118,17 +119,17 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         CrtBuildCtl ctl = { 0, 0, 0 };
         CrtBuildCtl* dCtl = dCtls + (level < kCtlLevels ? level : kCtlLevels - 1);
         if (level >= kCtlLevels - 1) HIPCHK(hipMemsetAsync(dCtl, 0, sizeof ctl, st));   // the shared last record (zero already on its first use: harmless)
-        ++level;
+        ++level; ++g.buildLevels;
         if (cnt[0]) {
             CrtBigScratch* big = bigs[cur]; const uint32_t* cn = chunkNode[cur];
-            crt_bvh_big_bins<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src);
-            crt_bvh_big_sweep<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, dst, chunkL);
-            crt_bvh_big_count<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, chunkL, chunkFR, chunkBL);
-            crt_bvh_big_tables<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, (uint32_t)firstTri, chunkFR, chunkBL, rank, holes, backL);
-            crt_bvh_big_scatter<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, dst, (uint32_t)firstTri, rank, holes, backL, end, dCtl, N, bigs[cur ^ 1], chunkNode[cur ^ 1]);
+            crt_bvh_big_bins<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src); ++g.buildLaunches;
+            crt_bvh_big_sweep<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, dst, chunkL); ++g.buildLaunches;
+            crt_bvh_big_count<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, chunkL, chunkFR, chunkBL); ++g.buildLaunches;
+            crt_bvh_big_tables<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, (uint32_t)firstTri, chunkFR, chunkBL, rank, holes, backL); ++g.buildLaunches;
+            crt_bvh_big_scatter<<<chunks, T, 0, st>>>(bn, L.list[0], big, cn, src, dst, (uint32_t)firstTri, rank, holes, backL, end, dCtl, N, bigs[cur ^ 1], chunkNode[cur ^ 1]); ++g.buildLaunches;
         }
-        if (cnt[1]) crt_bvh_mid<<<(cnt[1] + W - 1) / W, 64 * W, 0, st>>>(bn, L.list[1], cnt[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, &dCtl->packed, N);
-        if (cnt[2]) crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, &dCtl->packed, N);
+        if (cnt[1]) { crt_bvh_mid<<<(cnt[1] + W - 1) / W, 64 * W, 0, st>>>(bn, L.list[1], cnt[1], src, dst, (uint32_t)firstTri, rank, holes, backL, end, &dCtl->packed, N); ++g.buildLaunches; }
+        if (cnt[2]) { crt_bvh_tiny<<<(cnt[2] + 63) / 64, 64, 0, st>>>(bn, L.list[2], cnt[2], src, dst, end, &dCtl->packed, N); ++g.buildLaunches; }
         HIPCHK(hipGetLastError());
         if (replaying && (size_t)(level - 1) < g.buildReplay.size()) {
             // measurement hook (below): the level's list sizes are known from the recorded build of the same input -- no publish, no wait
@@ -137,7 +138,7 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
             // the level's list sizes: published into pinned memory behind the level's kernels; spin on the sequence number (a copy + stream
             // synchronisation per level cost ~40 us x 23 levels of a 1 M-triangle build), fall back to the stream if it does not arrive
             const uint32_t seq = ++g.buildSeq;
-            crt_bvh_publish<<<1, 1, 0, st>>>(dCtl, g.buildCtlHost, seq);
+            crt_bvh_publish<<<1, 1, 0, st>>>(dCtl, g.buildCtlHost, seq); ++g.buildLaunches;
             HIPCHK(hipGetLastError());
             bool arrived = false;
             for (unsigned spin = 0; spin < (1u << 22) && !g.buildNoSpin; ++spin) {
@@ -163,8 +164,8 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
             if (recording) g.buildReplay.push_back(ctl);
         }
         if (ctl.degenerate) {                                                      // BVH.cpp:194 hit a BIG node: its permuted triangles go to both buffers
-            crt_bvh_big_degenerate<<<chunks, T, 0, st>>>(bn, L.list[0], bigs[cur], chunkNode[cur], src, dst);
-            crt_bvh_big_degenerate_mark<<<(cnt[0] + 255) / 256, 256, 0, st>>>(bn, L.list[0], bigs[cur], cnt[0]);
+            crt_bvh_big_degenerate<<<chunks, T, 0, st>>>(bn, L.list[0], bigs[cur], chunkNode[cur], src, dst); ++g.buildLaunches;
+            crt_bvh_big_degenerate_mark<<<(cnt[0] + 255) / 256, 256, 0, st>>>(bn, L.list[0], bigs[cur], cnt[0]); ++g.buildLaunches;
         }
         for (int c = 0; c < 3; ++c) cnt[c] = bvh_unpack(ctl.packed, c);
         chunks = ctl.nextChunks;
@@ -184,18 +185,18 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
         if (nb > maxChunks) { (void)hipStreamSynchronize(st); return CRT_E_OUT_OF_RANGE; }
         HIPCHK(hipMemsetAsync(flags, 0, total * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(dScal, 0, 2 * sizeof(uint32_t), st));                     // [0] nodes used, [1] "a node number fell outside the node array"
-        crt_bvh_leaf_flags<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, (uint32_t)firstTri, flags);
-        crt_bvh_scan_sums<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums);
-        crt_bvh_scan_blocks<<<1, CRT_BVH_SCAN_THREADS, 0, st>>>(sums, nb);
-        crt_bvh_scan_apply<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums, S);
-        crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, numMeshes, S, (uint32_t)firstTri, (uint32_t)total, (uint32_t)firstNode, g.rawNodes, dRoots, dScal, dScal + 1);
+        crt_bvh_leaf_flags<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, (uint32_t)firstTri, flags); ++g.buildLaunches;
+        crt_bvh_scan_sums<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums); ++g.buildLaunches;
+        crt_bvh_scan_blocks<<<1, CRT_BVH_SCAN_THREADS, 0, st>>>(sums, nb); ++g.buildLaunches;
+        crt_bvh_scan_apply<<<nb, CRT_BVH_SCAN_THREADS, 0, st>>>(flags, (uint32_t)total, sums, S); ++g.buildLaunches;
+        crt_bvh_emit<<<(numBuilt + 255) / 256, 256, 0, st>>>(bn, numBuilt, numMeshes, S, (uint32_t)firstTri, (uint32_t)total, (uint32_t)firstNode, g.rawNodes, dRoots, dScal, dScal + 1); ++g.buildLaunches;
         HIPCHK(hipGetLastError());
     }
     uint32_t used = 0, scal[2] = { 0, 0 };
     HIPCHK(hipMemcpyAsync(scal, dScal, sizeof scal, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(g.roots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(g.hRoots + firstMesh, dRoots, (size_t)numMeshes * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    crt_relayout_tris<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.rawTris, firstTri, total, g.triHot, g.triCold);
+    crt_relayout_tris<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.rawTris, firstTri, total, g.triHot, g.triCold); ++g.buildLaunches;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     used = scal[0];

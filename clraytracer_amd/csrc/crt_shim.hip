@@ -151,6 +151,14 @@ int crt_debug_inject_failure(int device)
     return CRT_OK;
 }
 int crt_debug_staggered_frames(uint64_t* out) { NEED_SESSION(); if (!out) return CRT_E_BAD_ARGUMENT; Use u_(0); *out = g.staggeredFrames; return CRT_OK; }
+int crt_debug_build_stats(uint32_t* levels, uint32_t* launches)
+{
+    NEED_SESSION();
+    Use u_(0);
+    if (levels) *levels = g.buildLevels;
+    if (launches) *launches = g.buildLaunches;
+    return CRT_OK;
+}
 int crt_debug_last_gather(uint64_t* bytes, int* bytesPerPixel)
 {
     NEED_SESSION();

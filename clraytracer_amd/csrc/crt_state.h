@@ -106,6 +106,7 @@ struct State {
     void* queryBuf = nullptr; size_t queryBytes = 0;
     void* buildBuf = nullptr; size_t buildBytes = 0;          // crt_build_bvh scratch
     std::vector<CrtBuildCtl> buildReplay; unsigned long long buildReplayKey = 0;   // CRT_DEBUG_BVH_REPLAY (crt_bvh_driver.h): the level records of the last build
+    unsigned buildLaunches = 0, buildLevels = 0;   // crt_debug_build_stats: kernel launches and levels of the last crt_build_bvh (before the re-layout)
     bool buildNoSpin = false;                                   // the spin on buildCtlHost timed out once: synchronise the stream per level instead
     CrtBuildCtlHost* buildCtlHost = nullptr; uint32_t buildSeq = 0;   // pinned: the per-level control record the builder publishes (crt_bvh_publish)
     CrtTri* buildTris = nullptr;                               // crt_build_bvh: second triangle pool (same indexing as rawTris)

@@ -42,6 +42,9 @@ int crt_debug_last_kernel(char* dst, size_t cap);
  * float frame is rebuilt from them (x = byte / 255, bit for bit) only when crt_read_output / crt_output_device_ptr ask for it.
  * CRT_GATHER_RGBA8=0 in the environment keeps the float4 gather. 0 / 0 in a one-device session. */
 int crt_debug_last_gather(uint64_t* bytes, int* bytesPerPixel);
+/* Diagnostic: levels and kernel launches of the most recent crt_build_bvh on the session's first device (its own launches, before the
+ * re-layout for rendering): the build is launch-bound, bench.py reports both in `bvh_build`. */
+int crt_debug_build_stats(uint32_t* levels, uint32_t* launches);
 
 #ifdef __cplusplus
 }
