@@ -438,8 +438,24 @@ def main():
         hbm_frac = None if hbm_achieved is None else hbm_achieved / HBM_PEAK_GBS
         num_cus = int(hip.crt_device_name().decode().split(",")[-1].split()[0])
         # shader clock: measured beside frames in flight; CRT_SCLK_GHZ overrides; the 2.4 GHz nominal clock only as a last resort
-        clock_ghz = float(os.environ["CRT_SCLK_GHZ"]) if "CRT_SCLK_GHZ" in os.environ else (clock_meas or 2.4)
-        clock_src = "CRT_SCLK_GHZ" if "CRT_SCLK_GHZ" in os.environ else ("crt_debug_measure_clock: s_memtime / s_memrealtime beside 24 frames in flight" if clock_meas else "nominal (probe failed)")
+        # (r6: a run that skips the probe -- --timed-region-only, i.e. the kernel-trace passes under rocprofv3, where kernels are serialised and a probe
+        # "beside frames in flight" would measure nothing -- takes the clock the newest committed UN-profiled bench line measured, not the nominal one)
+        committed_clock = None
+        if clock_meas is None and "CRT_SCLK_GHZ" not in os.environ:
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_line.json")), reverse=True):
+                try:
+                    ch = (json.load(open(path)).get("roofline") or {}).get("chain") or {}
+                    if str(ch.get("clock_source", "")).startswith("crt_debug_measure_clock") and ch.get("clock_ghz"):
+                        committed_clock = (float(ch["clock_ghz"]), os.path.relpath(path, ROOT))
+                        break
+                except Exception:
+                    continue
+        clock_ghz = float(os.environ["CRT_SCLK_GHZ"]) if "CRT_SCLK_GHZ" in os.environ else (clock_meas or (committed_clock[0] if committed_clock else 2.4))
+        clock_src = "CRT_SCLK_GHZ" if "CRT_SCLK_GHZ" in os.environ else (
+            "crt_debug_measure_clock: s_memtime / s_memrealtime beside 24 frames in flight" if clock_meas else (
+                f"not measured in this run ({'--timed-region-only: probe skipped' if args.timed_region_only else 'probe failed'}); taken from the un-profiled line {committed_clock[1]}"
+                if committed_clock else f"NOMINAL 2.4 GHz ({'--timed-region-only: probe skipped' if args.timed_region_only else 'probe failed'}, no committed line to take it from): cycle-based figures are approximate"))
         ndev_here = n if inproc else 1                                          # in-process: counters are summed over the devices
         gather_rate = pair_fetches / ndev_here / (dev_s * clock_ghz * 1e9 * num_cus)   # 64-B records per cycle per CU
         warnings = []
@@ -729,6 +745,32 @@ def main():
                             sm.h.crth_end_instances()
                             sm.set_camera((0.0, 0.0, 23.0 * 6.0), scenes._normalize((0.0, 0.0, -1.0)))
                             mi[tl] = measure_view(sm, flags, 30, f"tiny's two meshes instanced 401 times on a grid, {width}x{height}, " + ("instance tree" if tl == "1" else "linear sphere loop"))
+                            if tl == "1":
+                                # ... and all 401 MOVING: upstream's Engine_Tick -> SetMeshPosition -> dirty range -> clEnqueueWriteBuffer (Renderer.cpp:268-298,312-320)
+                                # = crt_upload_instances before every frame. An upload is host-only (memcpy + rebuild_instance_master: bounding spheres, cull
+                                # ranges, the median-split instance tree); the frame's slot copies the new tables on its own stream.
+                                inst_m = sm.arenas()["instances"].copy()
+                                a_m, iv_m, ip_m = sm.trace_args()
+                                q_m = (C.byref(a_m), iv_m.ctypes.data_as(fp), ip_m.ctypes.data_as(fp))
+                                def many_animated(move, frames):
+                                    for _ in range(6):
+                                        crt_render(*q_m, flags)
+                                    _lib.check(hip.crt_sync(), "crt_sync")
+                                    t_up, t0 = 0.0, time.perf_counter()
+                                    for _ in range(frames):
+                                        if move:
+                                            inst_m["inv"][:, 3, 1] += np.float32(1e-4)
+                                            tu = time.perf_counter()
+                                            hip.crt_upload_instances(inst_m.ctypes.data, 0, len(inst_m))
+                                            t_up += time.perf_counter() - tu
+                                        r_ = crt_render(*q_m, flags)
+                                    _lib.check(hip.crt_sync(), "crt_sync"); _lib.check(r_, "crt_render")
+                                    return (time.perf_counter() - t0) / frames, t_up / frames
+                                (dts, _), (dtm, tup) = many_animated(False, 30), many_animated(True, 30)
+                                mi["animated"] = {"instances": len(inst_m), "value": round(mi["1"]["rays_per_frame"] / dtm / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dtm * 1e3, 4),
+                                                  "vs_static": round(dts / dtm, 3), "static_ms_per_step": round(dts * 1e3, 4), "host_tlas_rebuild_us": round(tup * 1e6, 1), "frames": 30,
+                                                  "workload": f"the same 401 instances, every one re-uploaded (crt_upload_instances) before every frame, frames in flight; host_tlas_rebuild_us = "
+                                                              "mean host time of that call (memcpy + bounding spheres + cull ranges + median-split instance tree, no device work); rays counted on the static scene"}
                 finally:
                     if saved_tlas is None:
                         os.environ.pop("CRT_TLAS", None)
@@ -737,6 +779,8 @@ def main():
                 out["many_instances"] = {"instances": 401, "value": mi["1"]["value"], "unit": "Mrays/s", "ms_per_step": mi["1"]["ms_per_step"],
                                          "rays_per_frame": mi["1"]["rays_per_frame"], "linear_loop": {"value": mi["0"]["value"], "ms_per_step": mi["0"]["ms_per_step"]},
                                          "tlas_vs_linear": round(mi["1"]["value"] / mi["0"]["value"], 3), "workload": mi["1"]["workload"]}
+                if "animated" in mi:
+                    out["animated_many_instances"] = mi["animated"]
             except Exception as e:  # pragma: no cover - an extra, never the reason for a missing line
                 out["many_instances"] = {"error": str(e)}
             s = driver.Session(width, height, device=device_index)
@@ -828,6 +872,14 @@ def main():
             # number of the line is final by now and this process's session is closed, so the children have the GPU to themselves; both passes
             # together get 60 s, after which (or on any failure) the committed profile's figure stays and the line says so.
             s.close()
+            # (every number of the line is final here -- keep a copy where a profiler hang or fault in the next seconds cannot take it)
+            try:
+                side = os.path.join(ROOT, "gpurun_out")
+                if os.path.isdir(side) and os.access(side, os.W_OK):
+                    with open(os.path.join(side, "bench_line_before_live_pmc.json"), "w") as f_side:
+                        json.dump(out, f_side)
+            except OSError:
+                pass
             live = live_pmc_traffic(sc.name, width, height, extra_args=["--frames-in-flight", flight, "--band-rows", args.band_rows, "--prewarm-ms", args.prewarm_ms],
                                     budget_s=float(os.environ.get("CRT_BENCH_LIVE_PMC_BUDGET_S", "60")))
             rl = out["roofline"]

@@ -104,18 +104,26 @@ def test_single_gpu_line_carries_the_contract_and_the_round_3_objects():
     assert r["vmem_pipe"] is None or 0 < r["vmem_pipe"]["busy_modelled"] < 1.5
     assert "stagger" in d["config"] and "3840x2160" in d["config"]["n_gt_1_lines"]
     for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "config3", "config2", "scale_base_n1",
-                "wavefront_compaction", "in_wave_refill", "in_wave_block_compaction"):
+                "wavefront_compaction", "in_wave_refill", "in_wave_block_compaction", "lds_tree_tops"):
         assert d[key]["value"] > 0 and d[key]["rays_per_frame"] > 0, key
     # every BASELINE config has its rocprof HBM figure: traffic from a committed profile of exactly that workload
     for key in ("with_shadow_rays", "dense_view", "reference_assets", "config3_with_shadow_rays", "config3", "config2", "scale_base_n1"):
         h = d[key]["hbm"]
         assert h is not None and h["traffic"] > 0 and 0 < h["frac"] <= 1.0 and h["traffic_source"].startswith("profiles/r") and 0 < h["l1_hit"] < 1 and 0 < h["l2_hit"] < 1, key
     # compaction three ways, each against the default kernel in the same mode
-    for key in ("wavefront_compaction", "in_wave_refill", "in_wave_block_compaction"):
+    # ... and north_star's LDS-staged tree tops (r6); every form names the kernel that rendered its frames and is divided by the default
+    # kernel measured the same way in the same loop
+    for key, kernel in (("wavefront_compaction", "crt_primary_kernel<"), ("in_wave_refill", "crt_trace_refill_kernel<"), ("in_wave_block_compaction", "crt_trace_block_kernel<"),
+                        ("lds_tree_tops", "crt_trace_ldstop_kernel<")):
         assert d[key]["vs_default_kernel_in_flight"] > 0 and d[key]["vs_default_synchronous"] > 0 and d[key]["rays_per_frame"] == d["config"]["rays_per_frame"], key
+        assert d[key]["kernel"].startswith(kernel) and d[key]["default_kernel_same_measurement"]["kernel"].startswith("crt_trace_kernel<"), key
+        assert abs(d[key]["vs_default_kernel"] - d[key]["value"] / d[key]["default_kernel_same_measurement"]["value"]) < 2e-3, key
     # SURVEY 8f rank 1's other half in the driver's record
     assert d["many_instances"]["instances"] == 401 and d["many_instances"]["value"] > 0 and d["many_instances"]["tlas_vs_linear"] > 1.0
     assert d["animated_instances"]["value"] > 0 and 0.3 < d["animated_instances"]["vs_static"] <= 1.1
+    am = d["animated_many_instances"]                                       # upstream's limit, all of them moving
+    assert am["instances"] == 401 and am["value"] > 0 and 0.2 < am["vs_static"] <= 1.1 and 0 < am["host_tlas_rebuild_us"] < 5000
+    assert d["bvh_build"]["launches"] > d["bvh_build"]["level_handshakes"] > 0
     assert 0 < d["bvh_build"]["ms"] < 100 and d["bvh_build"]["nodes"] > d["bvh_build"]["triangles"] and 0 < d["bvh_build"]["frac_of_hbm"] < 1
     assert d["wavefront_compaction"]["synchronous_frames"] > 0 and d["wavefront_compaction"]["rays_per_frame"] == d["config"]["rays_per_frame"]
     assert d["with_shadow_rays"]["shadow_rays_per_frame"] > 0 and d["dense_view"]["primary_hit_fraction"] > 0.9
