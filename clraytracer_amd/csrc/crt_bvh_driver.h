@@ -18,7 +18,9 @@ int crt1_build_bvh(size_t firstTri, const uint32_t* meshTriCounts, int numMeshes
     if (total / CRT_BVH_SMALL >= (1u << 20) || total / CRT_BVH_TINY >= (1u << 20)) return CRT_E_OUT_OF_RANGE;   // field widths of the packed per-level counter (crt_bvh_build.h)
     {   // test hook (CRT_DEBUG_HOOKS=1 only): refuse, so that the caller's fall-back to the host BuildBVH can be exercised
         const char* h = getenv("CRT_DEBUG_HOOKS"); const char* f = getenv("CRT_DEBUG_FAIL_BVH_BUILD");
-        if (h && atoi(h) != 0 && f && atoi(f) != 0) return CRT_E_OUT_OF_RANGE;
+        // CRT_DEBUG_FAIL_BVH_BUILD: 1 = CRT_E_OUT_OF_RANGE; any other non-zero value is returned as it is -- 2 (hipErrorOutOfMemory: the builder's
+        // scratch could not be allocated), -2 (CRT_E_BAD_ARGUMENT), 719 (hipErrorLaunchFailure: a sticky fault, the one kind the caller must not paper over)
+        if (h && atoi(h) != 0 && f && atoi(f) != 0) return atoi(f) == 1 ? (int)CRT_E_OUT_OF_RANGE : atoi(f);
     }
     RCCHK(sync_all());
     g.buildLaunches = 0; g.buildLevels = 0;

@@ -18,6 +18,26 @@ __global__ void crt_relayout_tris(const CrtTri* __restrict__ raw, size_t first, 
     cold[i * 2 + 1] = tail[1];
 }
 
+// Largest squared distance of a vertex of triangles [first, first + count) from the object-space origin, as the bits of a non-negative float
+// (atomicMax on the word orders them like the floats; NaN and overflow count as +inf). Hit points -- hence bounce-ray origins, hazard H6 -- lie on
+// triangles, so this bounds how far out a bounce ray can start whatever boxes were uploaded around them (crt_instances.h: bounceOriginReach).
+__global__ void crt_tri_reach_kernel(const CrtTri* __restrict__ raw, size_t first, size_t count, uint32_t* __restrict__ reachBits)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float m = 0.0f;
+    if (k < count) {
+        const CrtTri t = raw[first + k];
+        const float* v[3] = { t.v0, t.v1, t.v2 };
+        for (int c = 0; c < 3; ++c) {
+            float d2 = (v[c][0] * v[c][0] + v[c][1] * v[c][1]) + v[c][2] * v[c][2];
+            if (!(d2 == d2)) d2 = __uint_as_float(0x7F800000u);
+            m = d2 > m ? d2 : m;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reachBits, __float_as_uint(m));
+}
+
 // A reference that visits nothing: a leaf whose triangle count comes from bigLeaf[triCap], which crt_init sets to 0.
 // Used where an upload is inconsistent (a root index beyond the node array, a mesh without a tree, a malformed node):
 // such an instance or subtree renders as empty instead of testing whatever triangle 0 happens to be.

@@ -83,7 +83,8 @@ struct State {
     // Range of ray origins for which the instance cull is provably exact (derivation: crt_device.h above sphere_culls):
     // per instance and the smallest over the cullable ones; a frame / query whose origins lie beyond it runs with `noCullBounds`.
     float hCullOriginLimit[CRT_MAX_INSTANCES]; float cullOriginLimit = 0.0f; float bounceOriginReach = 0.0f;
-    double triReach2 = 0.0;                    // largest squared distance of an uploaded vertex from its object-space origin (crt1_upload_triangles)
+    double triReach2 = 0.0;                    // largest squared distance of a vertex in the triangle pool from its object-space origin (crt1_upload_triangles)
+    uint32_t* triReachBits = nullptr;          // device: that maximum as float bits (crt_tri_reach_kernel)
     float4* noCullBounds = nullptr;            // device: CRT_MAX_INSTANCES x (0, 0, 0, -1) = "never cull"
     unsigned long long noCullFrames = 0;       // frames and queries that ran without the cull for that reason
     CrtMeshInstance hInstances[CRT_MAX_INSTANCES]; uint32_t hRoots[CRT_MAX_MESHES]; uint32_t instHigh = 0;

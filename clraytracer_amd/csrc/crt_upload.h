@@ -49,6 +49,7 @@ static int init_impl(int device, int width, int height)
     g.nodeCap = (size_t)CRT_MAX_TRIANGLES * 2;          // ResourceManager.cpp:159 (MAX_BVHMEMORY * 2)
     g.texelByteCap = CRT_MAX_TEXTURE_BYTES * 2;         // ResourceManager.cpp:163
     HIPCHK(hipMalloc(&g.rawTris, g.triCap * sizeof(CrtTri)));
+    HIPCHK(hipMemsetAsync(g.rawTris, 0, g.triCap * sizeof(CrtTri), g.stream));   // crt_tri_reach_kernel may scan slots nobody has uploaded yet (an upload that leaves a gap)
     HIPCHK(hipMalloc(&g.rawNodes, g.nodeCap * sizeof(CrtBVHNode)));
     HIPCHK(hipMalloc(&g.roots, CRT_MAX_MESHES * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&g.rawTexels, g.texelByteCap + 16));
@@ -66,6 +67,8 @@ static int init_impl(int device, int width, int height)
     HIPCHK(hipMalloc(&g.textures, CRT_MAX_TEXTURES * sizeof(CrtTexture)));
     HIPCHK(hipMalloc(&g.counters, CRT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&g.err, sizeof(int)));
+    HIPCHK(hipMalloc(&g.triReachBits, sizeof(uint32_t)));
+    HIPCHK(hipMemset(g.triReachBits, 0, sizeof(uint32_t)));
     {   // the "never cull" bounds table of frames whose rays start beyond the cull's proven range
         static float4 never[CRT_MAX_INSTANCES];
         for (float4& b : never) b = make_float4(0.f, 0.f, 0.f, -1.0f);
@@ -121,7 +124,7 @@ static void release_all()
 {
     for (FrameSlot& fs : g.slot) if (fs.stream) (void)hipStreamSynchronize(fs.stream);
     void* ptrs[] = { g.rawTris, g.rawNodes, g.roots, g.rawTexels, g.pairs, g.triHot, g.triCold, g.bigLeaf, g.rootRefs,
-                     g.texels, g.materials, g.textures, g.rays, g.counters, g.err, g.topPairs, g.topRootRefs,
+                     g.texels, g.materials, g.textures, g.rays, g.counters, g.err, g.triReachBits, g.topPairs, g.topRootRefs,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.noCullBounds };
     for (FrameSlot& fs : g.slot) {
         void* q[] = { fs.out, fs.aux, fs.blockQueue, fs.wfCount, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
@@ -182,20 +185,26 @@ int crt1_upload_triangles(const void* tris, size_t byteOffset, size_t bytes)
     crt_relayout_tris<<<(unsigned)((count + 255) / 256), 256, 0, g.stream>>>(g.rawTris, first, count, g.triHot, g.triCold);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(g.stream));
+    // How far from the object-space origin a vertex (hence a hit point, hence a bounce-ray origin, hazard H6) can lie: the cull's proven range is
+    // checked against this as well as against the root boxes, so that nodes uploaded through crt_upload_bvh_nodes whose boxes do not bound their
+    // triangles cannot take bounce origins beyond it. Reduced on the device from the pool itself (r6, ADVICE r5: it used to be a serial host
+    // scan per upload and per device state, and could only grow): an upload that appends folds its own range in; one that overwrites triangles
+    // uploaded before recomputes over the whole pool, so a far vertex that has been replaced stops counting.
+    const bool overwrites = first < g.trisHigh;
     if (first + count > g.trisHigh) g.trisHigh = first + count;
-    {   // how far from the object-space origin a vertex (hence a hit point, hence a bounce-ray origin, hazard H6) can lie: the cull's
-        // proven range is checked against this as well as against the root boxes, so that nodes uploaded through crt_upload_bvh_nodes
-        // whose boxes do not bound their triangles cannot take bounce origins beyond it. Monotonic until the next crt_init.
-        const float* v = static_cast<const float*>(tris);
-        double far2 = g.triReach2;
-        bool bad = false;
-        for (size_t t = 0; t < count; ++t, v += sizeof(CrtTri) / sizeof(float))
-            for (int k = 0; k < 3; ++k) {
-                const double x = v[4 * k], y = v[4 * k + 1], z = v[4 * k + 2], d2 = x * x + y * y + z * z;
-                if (!(d2 == d2)) bad = true; else if (d2 > far2) far2 = d2;
-            }
-        if (bad) far2 = 1e300;
-        if (far2 > g.triReach2) { g.triReach2 = far2; rebuild_instance_master(); }
+    if (overwrites) HIPCHK(hipMemsetAsync(g.triReachBits, 0, sizeof(uint32_t), g.stream));
+    {
+        const size_t f0 = overwrites ? 0 : first, n0 = overwrites ? g.trisHigh : count;
+        crt_tri_reach_kernel<<<(unsigned)((n0 + 255) / 256), 256, 0, g.stream>>>(g.rawTris, f0, n0, g.triReachBits);
+        HIPCHK(hipGetLastError());
+    }
+    uint32_t bitsHost = 0;
+    HIPCHK(hipMemcpyAsync(&bitsHost, g.triReachBits, sizeof bitsHost, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    {
+        float f; memcpy(&f, &bitsHost, sizeof f);
+        const double far2 = (f == f && f < 3.0e38f) ? (double)f * (1.0 + 1e-6) : 1e300;     // (fp32 sum of three squares: 3 roundings; inf / NaN: unbounded)
+        if (far2 != g.triReach2) { g.triReach2 = far2; rebuild_instance_master(); }
     }
     return CRT_OK;
 }

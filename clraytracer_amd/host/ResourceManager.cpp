@@ -335,12 +335,16 @@ void ResourceManager::PushMeshesToGPU() // ResourceManager.cpp:280-300
         int rc = crt_upload_triangles(g_Triangles + lastTriangleCount, lastTriangleCount * sizeof(Tri), addedTriangleSize);
         int built = rc;
         if (rc == 0) built = crt_build_bvh(lastTriangleCount, counts, newMeshes, lastBVHIndex, numberOfBVH, &numNodesUsed);
-        if (rc == 0 && (built == CRT_E_OUT_OF_RANGE || built == CRT_E_UNSUPPORTED)) {
-            // the device builder REFUSED (a size beyond its scratch layout, or its consistency checks): the host arenas still hold the
-            // triangles as imported, so the host BuildBVH below takes over and its uploads replace whatever the device build left behind
-            std::fprintf(stderr, "[ResourceManager] crt_build_bvh refused (%d): building on the host\n", built);
+        // Refusals: a size beyond the builder's scratch layout or a failed consistency check (OUT_OF_RANGE, UNSUPPORTED), an argument it does not
+        // take (BAD_ARGUMENT: e.g. a mesh without triangles), or its own scratch / second triangle pool not fitting (hipErrorOutOfMemory = 2, not sticky:
+        // the device is as usable as before) -- ADVICE r5. The host arenas still hold the triangles as imported, so the host BuildBVH below takes
+        // over and its uploads replace whatever the device build left behind.
+        const bool refused = built == CRT_E_OUT_OF_RANGE || built == CRT_E_UNSUPPORTED || built == CRT_E_BAD_ARGUMENT || built == 2 /* hipErrorOutOfMemory */;
+        if (rc == 0 && refused) {
+            std::fprintf(stderr, "[ResourceManager] crt_build_bvh refused (%d: %s): building on the host\n", built, crt_error_string(built));
         } else if (rc == 0 && built != 0) {
-            // anything else (a HIP error: a faulting kernel, a failed stream synchronisation) is reported where it happened, not papered over
+            // anything else (a sticky HIP error: a faulting kernel, a failed stream synchronisation) is reported where it happened, not papered over:
+            // lastError is set and the arenas stay as they were (nothing of this push is marked as built)
             note(built, "crt_build_bvh");
             return;
         } else {

@@ -196,11 +196,21 @@ def test_a_refused_device_build_falls_back_to_the_host_builder(monkeypatch, capf
         a = s.arenas()
         want_nodes, want_tris = a["nodes"].tobytes(), a["tris"].tobytes()
         s.render_raw(0); want = s.read_output().copy()
-    monkeypatch.setenv("CRT_DEBUG_HOOKS", "1"); monkeypatch.setenv("CRT_DEBUG_FAIL_BVH_BUILD", "1")
+    monkeypatch.setenv("CRT_DEBUG_HOOKS", "1")
+    # refusal codes: OUT_OF_RANGE (1 -> -3), the builder's scratch not fitting (hipErrorOutOfMemory = 2), BAD_ARGUMENT (-2) -- ADVICE r5
+    for code in ("1", "2", "-2"):
+        monkeypatch.setenv("CRT_DEBUG_FAIL_BVH_BUILD", code)
+        with driver.Session(160, 96, device=0) as s:
+            s.load_scene(sc, device_bvh_build=True)
+            a = s.arenas()
+            assert a["nodes"].tobytes() == want_nodes and a["tris"].tobytes() == want_tris, code
+            s.render_raw(0)
+            assert np.array_equal(s.read_output().view(np.uint32), want.view(np.uint32)), code
+        assert "building on the host" in capfd.readouterr().err, code
+    # a sticky HIP error (719 = hipErrorLaunchFailure) is NOT papered over: PushMeshesToGPU reports it, nothing of the push counts as built
+    monkeypatch.setenv("CRT_DEBUG_FAIL_BVH_BUILD", "719")
     with driver.Session(160, 96, device=0) as s:
-        s.load_scene(sc, device_bvh_build=True)
-        a = s.arenas()
-        assert a["nodes"].tobytes() == want_nodes and a["tris"].tobytes() == want_tris
-        s.render_raw(0)
-        assert np.array_equal(s.read_output().view(np.uint32), want.view(np.uint32))
-    assert "building on the host" in capfd.readouterr().err
+        with pytest.raises(driver.CrtError) as ei:
+            s.load_scene(sc, device_bvh_build=True)
+        assert "719" in str(ei.value)
+        assert s.h.crth_last_error() == 719 and s.h.crth_num_nodes() == 0          # lastError set, node arena untouched

@@ -45,4 +45,10 @@ def test_plain_trace_instantiations_need_no_scratch_and_64_vgprs():
     assert r["ScratchSize"] == 0 and r["VGPRs"] <= 64 and r["Occupancy"] == 8 and r["LDS Size"] == 5120, r
     for name in ("crt_primary_kernel<false>", "crt_bounce_kernel<false>"):
         assert rows[name]["ScratchSize"] == 0 and rows[name]["VGPRs"] <= 64 and rows[name]["Occupancy"] == 8, (name, rows[name])
-    assert rows["crt_trace_block_kernel<false, false>"]["VGPRs"] <= 64 and rows["crt_trace_block_kernel<false, false>"]["Occupancy"] == 8
+    # the block form keeps occupancy 8 at the price of a small spill (7 VGPRs = 32 B of scratch per lane, stated in DESIGN.md 4f: its 0.81x is
+    # measured WITH that spill)
+    r = rows["crt_trace_block_kernel<false, false>"]
+    assert r["VGPRs"] <= 64 and r["Occupancy"] == 8 and r["ScratchSize"] <= 32, r
+    # round 6: the LDS-staged tree tops -- four waves per workgroup, 15.75 KiB table + 4 x 3.75 KiB of stack = 30.75 KiB -> five workgroups per CU
+    r = rows["crt_trace_ldstop_kernel<false>"]
+    assert r["ScratchSize"] == 0 and r["VGPRs"] <= 96 and r["Occupancy"] == 5 and r["LDS Size"] == 252 * 64 + 4 * 15 * 256, r
