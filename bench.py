@@ -115,8 +115,11 @@ def main():
     flight = args.frames_in_flight if args.frames_in_flight > 0 else (3 if n < 4 else 8)
     flight = max(1, min(8, flight))
     os.environ["CRT_FRAMES_IN_FLIGHT"] = str(flight)   # read by crt_init
-    if flight > 4:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # one hardware queue per slot's stream; read by the HIP runtime at its first call
+    # One hardware queue per slot's stream; read by the HIP runtime at its first call. Always (r6), not only for more than four slots: with the
+    # runtime's default of four queues two of the THREE slot streams occasionally land on one queue (other streams of the process take queues
+    # too) and their frames serialise -- one line of round 6's evidence run read nanosuit-demo at 12.6 instead of 16.6 Gray/s that way, which is
+    # exactly what GPU_MAX_HW_QUEUES=2 reproduces (profiles/r06_hw_queues.txt); eight queues measure the same as four when nothing collides.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import ctypes as C
     import numpy as np

@@ -13,6 +13,11 @@ import os
 
 import numpy as np
 
+# One hardware queue per frame slot's stream (read by the HIP runtime at its first call in the process; never overrides the caller's setting):
+# with the runtime's default of four queues two of the three slot streams occasionally share one and their frames serialise
+# (profiles/r06_hw_queues.txt: 16.6 -> 12.3 Gray/s on nanosuit-demo, the same as GPU_MAX_HW_QUEUES=2).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HIP_SO = os.path.join(_HERE, "csrc", "libcrt_hip.so")

@@ -71,10 +71,11 @@ int crt_band_plan(int height, int bandRows, int rank, int nRanks, int out[4])
 // More than four frame slots want one hardware queue per slot stream; the HIP runtime reads GPU_MAX_HW_QUEUES when it starts
 // (its first call in the process), so this must run before any HIP call: both initialisers call it first. A caller that
 // has already used HIP (e.g. through another library) must export the variable itself.
+// (r6: raised for every session, not only for more than four slots -- with the default of four queues two of three slot streams can end up on
+// one queue, whose frames then serialise: 16.6 -> 12.3 Gray/s on nanosuit-demo, profiles/r06_hw_queues.txt. Never overrides the caller's setting.)
 static void raise_hw_queues()
 {
-    const char* e = getenv("CRT_FRAMES_IN_FLIGHT");
-    if (e && atoi(e) > 4) (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
 }
 
 int crt_init_devices(const int* devices, int numDevices, int width, int height)

@@ -176,14 +176,17 @@ def _node_barrier_worker(rank, world, port, outdir):
                 time.sleep(0.002)                                    # a straggler
             nb.wait()
             assert log[1 - rank, k] == k + 1, (rank, k)              # ... and so has the other rank, before I leave it
-        over = []
-        for _ in range(50):
-            nb.wait(); t0 = time.perf_counter()
-            t_end = t0 + 0.001
-            while time.perf_counter() < t_end:
-                pass
-            nb.wait(); over.append(time.perf_counter() - t0 - 0.001)
-        np.save(os.path.join(outdir, f"over{rank}.npy"), np.array(over))
+        def region_overhead(bar):
+            over = []
+            for _ in range(50):
+                bar(); t0 = time.perf_counter()
+                t_end = t0 + 0.001
+                while time.perf_counter() < t_end:
+                    pass
+                bar(); over.append(time.perf_counter() - t0 - 0.001)
+            return np.array(over)
+        np.save(os.path.join(outdir, f"over{rank}.npy"), region_overhead(nb.wait))
+        np.save(os.path.join(outdir, f"gloo{rank}.npy"), region_overhead(dist.barrier))
         nb.close()
         dist.barrier()
     finally:
@@ -196,7 +199,9 @@ def test_node_barrier_between_two_ranks(tmp_path):
     np.save(tmp_path / "log.npy", np.zeros((2, 200), np.int64))
     mp.spawn(_node_barrier_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     over = np.concatenate([np.load(tmp_path / f"over{r}.npy") for r in range(world)])
-    assert np.median(over) < 200e-6, np.median(over)                  # microseconds, not a TCP round trip (bound loose: CI hosts are busy)
+    gloo = np.concatenate([np.load(tmp_path / f"gloo{r}.npy") for r in range(world)])
+    # microseconds, not a TCP round trip -- judged against the gloo barrier measured the same way on the same (possibly busy) host
+    assert np.median(over) < max(200e-6, 0.5 * np.median(gloo)), (np.median(over), np.median(gloo))
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("crt_bench_")]      # the creating rank unlinked the object
 
 
