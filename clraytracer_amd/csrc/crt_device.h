@@ -295,7 +295,7 @@ __device__ __forceinline__ v3 mat3mul(const CrtDevInstance& m, v3 v)
 // lanes share their first candidates and mostly hit the same instance -- and through four per-lane vector loads otherwise:
 // vector-memory instructions are what bounds the kernel, and unlike the node fetches (where the same test
 // cost more than it saved, round 2) instance records are fetched rarely enough for one readfirstlane + compare + ballot
-// per step to pay. (The table is written by crt_relayout_instances in an earlier launch, never by the reading kernel.)
+// per step to pay. (The table is written by crt_refresh_instances_kernel in an earlier launch, never by the reading kernel.)
 __device__ __forceinline__ CrtDevInstance load_instance(const CrtDevInstance* __restrict__ table, uint32_t inst)
 {
     CrtDevInstance I;

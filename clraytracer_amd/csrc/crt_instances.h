@@ -205,11 +205,12 @@ void rebuild_instance_master()
 }
 
 // Offsets of the tables inside a slot's pinned staging block
+// (r6: one block on the device with the same layout, the instance tree last, so a refresh is ONE copy of the used extent instead of four)
 constexpr size_t kStageInst = 0;
 constexpr size_t kStageBounds = (kStageInst + CRT_MAX_INSTANCES * sizeof(CrtMeshInstance) + 255) & ~(size_t)255;
-constexpr size_t kStageTlas = (kStageBounds + CRT_MAX_INSTANCES * sizeof(float4) + 255) & ~(size_t)255;
-constexpr size_t kStageAlways = (kStageTlas + 2 * CRT_MAX_INSTANCES * sizeof(CrtTlasNode) + 255) & ~(size_t)255;
-constexpr size_t kStageBytes = kStageAlways + CRT_MAX_INSTANCES * sizeof(uint32_t);
+constexpr size_t kStageAlways = (kStageBounds + CRT_MAX_INSTANCES * sizeof(float4) + 255) & ~(size_t)255;
+constexpr size_t kStageTlas = (kStageAlways + CRT_MAX_INSTANCES * sizeof(uint32_t) + 255) & ~(size_t)255;
+constexpr size_t kStageBytes = kStageTlas + 2 * CRT_MAX_INSTANCES * sizeof(CrtTlasNode);
 
 // Brings a slot's instance tables up to the host master, on the slot's own stream, before a frame (or query) uses them.
 int ensure_slot_instances(FrameSlot& fs)
@@ -218,15 +219,16 @@ int ensure_slot_instances(FrameSlot& fs)
     HIPCHK(hipEventSynchronize(fs.staged));                        // the previous refresh no longer reads the staging block
     memcpy(fs.staging + kStageInst, g.hInstances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance));
     memcpy(fs.staging + kStageBounds, g.hBounds, CRT_MAX_INSTANCES * sizeof(float4));
-    if (g.hTlasNodes) memcpy(fs.staging + kStageTlas, g.hTlas, g.hTlasNodes * sizeof(CrtTlasNode));
     if (g.hNumAlways) memcpy(fs.staging + kStageAlways, g.hAlways, g.hNumAlways * sizeof(uint32_t));
-    HIPCHK(hipMemcpyAsync(fs.instances, fs.staging + kStageInst, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance), hipMemcpyHostToDevice, fs.stream));
-    HIPCHK(hipMemcpyAsync(fs.instBounds, fs.staging + kStageBounds, CRT_MAX_INSTANCES * sizeof(float4), hipMemcpyHostToDevice, fs.stream));
-    if (g.hTlasNodes) HIPCHK(hipMemcpyAsync(fs.tlas, fs.staging + kStageTlas, g.hTlasNodes * sizeof(CrtTlasNode), hipMemcpyHostToDevice, fs.stream));
-    if (g.hNumAlways) HIPCHK(hipMemcpyAsync(fs.alwaysList, fs.staging + kStageAlways, g.hNumAlways * sizeof(uint32_t), hipMemcpyHostToDevice, fs.stream));
-    HIPCHK(hipEventRecord(fs.staged, fs.stream));
-    crt_relayout_instances<<<(CRT_MAX_INSTANCES + 255) / 256, 256, 0, fs.stream>>>(fs.instances, g.rootRefs, g.topRootRefs, CRT_MAX_INSTANCES, fs.devInstances);
+    if (g.hTlasNodes) memcpy(fs.staging + kStageTlas, g.hTlas, g.hTlasNodes * sizeof(CrtTlasNode));
+    // every frame of an animated scene pays this (upstream: Renderer.cpp:312-320, one clEnqueueWriteBuffer of the dirty range): ONE small launch that
+    // reads the pinned block over the link, fills the device block and builds the device records (crt_refresh_instances_kernel)
+    static_assert(kStageInst == 0 && kStageBytes % 16 == 0 && kStageTlas % 16 == 0 && sizeof(CrtTlasNode) % 16 == 0, "copied as 16-byte words");
+    const uint32_t words16 = (uint32_t)((kStageTlas + g.hTlasNodes * sizeof(CrtTlasNode)) / 16);
+    crt_refresh_instances_kernel<<<16, 256, 0, fs.stream>>>(reinterpret_cast<const uint4*>(fs.stagingDev), reinterpret_cast<uint4*>(fs.instBlock), words16,
+                                                             g.rootRefs, g.topRootRefs, CRT_MAX_INSTANCES, fs.devInstances);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(fs.staged, fs.stream));
     fs.tlasNodes = g.hTlasNodes; fs.numAlways = g.hNumAlways; fs.instVersion = g.instVersion;
     return CRT_OK;
 }

@@ -87,17 +87,23 @@ __global__ void crt_make_root_refs(const CrtBVHNode* __restrict__ raw, uint32_t 
     rootRefs[k] = make_ref(raw[r], r, nodeCount, triCap, bigLeaf, err);
 }
 
-// (r2.w: the mesh's root as a reference into the tree-top table, or the same global reference as r0.w -- read by CRT_KERNEL=ldstop only)
-__global__ void crt_relayout_instances(const CrtMeshInstance* __restrict__ raw, const uint32_t* __restrict__ rootRefs, const uint32_t* __restrict__ topRootRefs,
-                                       uint32_t count, CrtDevInstance* __restrict__ out)
+// Refresh of a frame slot's instance tables in ONE launch (r6): the slot's pinned staging block (raw instance records, bounding spheres, never-culled
+// list, instance tree: crt_instances.h kStage*) is read over the host link by this kernel, copied into the slot's device block, and the 64-byte device
+// records are built from the raw ones on the way -- where rounds 2-5 queued up to four hipMemcpyAsync (SDMA packets, ~10 us of stream latency each)
+// and a relayout launch in front of every frame of an animated scene (upstream: one clEnqueueWriteBuffer, Renderer.cpp:312-320).
+__global__ void crt_refresh_instances_kernel(const uint4* __restrict__ staging, uint4* __restrict__ block, uint32_t words16,
+                                             const uint32_t* __restrict__ rootRefs, const uint32_t* __restrict__ topRootRefs,
+                                             uint32_t count, CrtDevInstance* __restrict__ out)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t k = i; k < words16; k += stride) block[k] = staging[k];
     if (i >= count) return;
-    const CrtMeshInstance m = raw[i];
+    const CrtMeshInstance m = reinterpret_cast<const CrtMeshInstance*>(staging)[i];      // (kStageInst = 0: the raw records lead the block)
     const uint32_t mesh = m.meshIndex < CRT_MAX_MESHES ? m.meshIndex : 0;
     CrtDevInstance d;
     d.r0 = make_float4(m.inverseTransform.m[0][0], m.inverseTransform.m[0][1], m.inverseTransform.m[0][2], __uint_as_float(rootRefs[mesh]));
     d.r1 = make_float4(m.inverseTransform.m[1][0], m.inverseTransform.m[1][1], m.inverseTransform.m[1][2], __uint_as_float((uint32_t)m.materialStart));
+    // (r2.w: the mesh's root as a reference into the tree-top table, or the same global reference as r0.w -- read by CRT_KERNEL=ldstop only)
     d.r2 = make_float4(m.inverseTransform.m[2][0], m.inverseTransform.m[2][1], m.inverseTransform.m[2][2], __uint_as_float(topRootRefs[mesh]));
     d.r3 = make_float4(m.inverseTransform.m[3][0], m.inverseTransform.m[3][1], m.inverseTransform.m[3][2], 0.0f);
     out[i] = d;

@@ -33,10 +33,12 @@ struct FrameSlot {
     // This slot's copy of the instance tables (reference-layout records, device records, bounding spheres, instance tree,
     // never-culled list), refreshed on the slot's own stream from the host master when it is stale (ensure_slot_instances):
     // an instance upload never has to wait for the frames in flight, and those frames never see it.
+    char* instBlock = nullptr;                 // one device allocation; the four pointers below point into it
     CrtMeshInstance* instances = nullptr; CrtDevInstance* devInstances = nullptr; float4* instBounds = nullptr;
     CrtTlasNode* tlas = nullptr; uint32_t* alwaysList = nullptr; uint32_t tlasNodes = 0, numAlways = 0;
     unsigned long long instVersion = 0;        // 0 = never filled (the master starts at 1)
     uint32_t* mixOrder = nullptr; uint32_t* mixLen = nullptr; size_t mixCap = 0; int mixSlots = -1;   // CRT_RENDER_DIAG_MIX3 launch lists
+    char* stagingDev = nullptr;                // the staging block as the device sees it
     char* staging = nullptr; hipEvent_t staged = nullptr;   // pinned staging block and "its copies have been issued and done" event
     // in-process multi-GPU (crt_init_devices): a secondary device records `partDone` behind the copy of its bands into the
     // primary's frame; the primary records `slotDone` behind everything a frame queues on this slot (incl. a read-back)

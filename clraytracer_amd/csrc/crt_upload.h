@@ -30,12 +30,12 @@ static int init_impl(int device, int width, int height)
         FrameSlot& fs = g.slot[si];
         HIPCHK(hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
         for (EventSet& es : fs.es) for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&es.ev[i]));
-        HIPCHK(hipMalloc(&fs.instances, CRT_MAX_INSTANCES * sizeof(CrtMeshInstance)));
+        HIPCHK(hipMalloc(&fs.instBlock, kStageBytes));         // the slot's instance tables in the staging block's layout (crt_instances.h)
+        fs.instances = reinterpret_cast<CrtMeshInstance*>(fs.instBlock + kStageInst); fs.instBounds = reinterpret_cast<float4*>(fs.instBlock + kStageBounds);
+        fs.alwaysList = reinterpret_cast<uint32_t*>(fs.instBlock + kStageAlways); fs.tlas = reinterpret_cast<CrtTlasNode*>(fs.instBlock + kStageTlas);
         HIPCHK(hipMalloc(&fs.devInstances, CRT_MAX_INSTANCES * sizeof(CrtDevInstance)));
-        HIPCHK(hipMalloc(&fs.instBounds, CRT_MAX_INSTANCES * sizeof(float4)));
-        HIPCHK(hipMalloc(&fs.tlas, 2 * CRT_MAX_INSTANCES * sizeof(CrtTlasNode)));
-        HIPCHK(hipMalloc(&fs.alwaysList, CRT_MAX_INSTANCES * sizeof(uint32_t)));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&fs.staging), kStageBytes, hipHostMallocDefault));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&fs.stagingDev), fs.staging, 0));     // the refresh kernel reads the pinned block itself
         HIPCHK(hipEventCreateWithFlags(&fs.staged, hipEventDisableTiming));
         HIPCHK(hipEventRecord(fs.staged, fs.stream));
         HIPCHK(hipEventCreateWithFlags(&fs.partDone, hipEventDisableTiming));
@@ -127,7 +127,7 @@ static void release_all()
                      g.texels, g.materials, g.textures, g.rays, g.counters, g.err, g.triReachBits, g.topPairs, g.topRootRefs,
                      g.queryBuf, g.buildBuf, g.buildTris, g.stamps, g.noCullBounds };
     for (FrameSlot& fs : g.slot) {
-        void* q[] = { fs.out, fs.aux, fs.blockQueue, fs.wfCount, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instances, fs.devInstances, fs.instBounds, fs.tlas, fs.alwaysList };
+        void* q[] = { fs.out, fs.aux, fs.blockQueue, fs.wfCount, fs.ovf, fs.order, fs.len, fs.cost, fs.mixOrder, fs.mixLen, fs.packBuf, fs.instBlock, fs.devInstances };
         for (void* p : q) if (p) (void)hipFree(p);
         if (fs.staging) (void)hipHostFree(fs.staging);
         if (fs.staged) (void)hipEventDestroy(fs.staged);
