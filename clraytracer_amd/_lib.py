@@ -74,6 +74,7 @@ HIP_API = {
     "crt_debug_last_kernel": (C.c_int, [C.c_char_p, C.c_size_t]),
     "crt_debug_last_gather": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "crt_debug_build_stats": (C.c_int, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "crt_debug_tlas_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "crt_debug_measure_clock": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "crt_shutdown": (C.c_int, []),
     "crt_resize": (C.c_int, [C.c_int, C.c_int]),

@@ -207,7 +207,7 @@ def run(ctx):
                             mi["animated"] = {"instances": len(inst_m), "value": round(mi["1"]["rays_per_frame"] / dtm / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dtm * 1e3, 4),
                                               "vs_static": round(dts / dtm, 3), "static_ms_per_step": round(dts * 1e3, 4), "host_tlas_rebuild_us": round(tup * 1e6, 1), "frames": 30,
                                               "workload": f"the same 401 instances, every one re-uploaded (crt_upload_instances) before every frame, frames in flight; host_tlas_rebuild_us = "
-                                                          "mean host time of that call (memcpy + bounding spheres + cull ranges + median-split instance tree, no device work); rays counted on the static scene"}
+                                                          "mean host time of that call (memcpy + bounding spheres + cull ranges + instance-tree refit, no device work); rays counted on the static scene"}
             finally:
                 if saved_tlas is None:
                     os.environ.pop("CRT_TLAS", None)

@@ -152,6 +152,15 @@ int crt_debug_inject_failure(int device)
     return CRT_OK;
 }
 int crt_debug_staggered_frames(uint64_t* out) { NEED_SESSION(); if (!out) return CRT_E_BAD_ARGUMENT; Use u_(0); *out = g.staggeredFrames; return CRT_OK; }
+int crt_debug_tlas_stats(uint64_t* builds, uint32_t* refitsSinceBuild, uint32_t* nodes)
+{
+    NEED_SESSION();
+    Use u_(0);
+    if (builds) *builds = g.hTlasBuilds;
+    if (refitsSinceBuild) *refitsSinceBuild = g.hTlasRefits;
+    if (nodes) *nodes = g.hTlasNodes;
+    return CRT_OK;
+}
 int crt_debug_build_stats(uint32_t* levels, uint32_t* launches)
 {
     NEED_SESSION();

@@ -80,6 +80,10 @@ struct State {
     // host master of everything derived from the instance table (rebuild_instance_master); slots copy it when stale
     float4 hBounds[CRT_MAX_INSTANCES]; CrtTlasNode hTlas[2 * CRT_MAX_INSTANCES]; uint32_t hAlways[CRT_MAX_INSTANCES];
     uint32_t hTlasNodes = 0, hNumAlways = 0; unsigned long long instVersion = 1;
+    // incremental rebuild_instance_master (r6): the reach the limits were checked against, and what the instance tree was last BUILT for (it is refitted while
+    // the set of cullable instances stays the same)
+    double hReach = 0.0; bool hTlasBuilt = false; uint32_t hTlasBuiltHigh = 0, hTlasRefits = 0; double hTlasBuiltRadii = 0.0; uint8_t hTlasMember[CRT_MAX_INSTANCES] = { 0 };
+    unsigned long long hTlasBuilds = 0;        // median-split builds so far (crt_debug_tlas_stats)
     CrtBVHNode hRootNodes[CRT_MAX_MESHES]; bool hHaveRoot[CRT_MAX_MESHES];   // root node of every mesh, cached at BVH upload
     CrtBVHNode hRootKids[CRT_MAX_MESHES][2]; bool hHaveKids[CRT_MAX_MESHES];  // ... and the root's two children: their boxes are what an entering ray is tested against
     // Range of ray origins for which the instance cull is provably exact (derivation: crt_device.h above sphere_culls):

@@ -291,7 +291,7 @@ int crt1_upload_instances(const void* instances, size_t first, size_t count)
     // slot) refreshes its slot's copy on its own stream first -- an animated scene stays pipelined
     memcpy(g.hInstances + first, instances, count * sizeof(CrtMeshInstance));
     if (first + count > g.instHigh) g.instHigh = (uint32_t)(first + count);
-    rebuild_instance_master();
+    rebuild_instance_master((uint32_t)first, (uint32_t)count, false);      // only the records that were replaced (+ a refit of the instance tree)
     return CRT_OK;
 }
 

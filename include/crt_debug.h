@@ -45,6 +45,11 @@ int crt_debug_last_gather(uint64_t* bytes, int* bytesPerPixel);
 /* Diagnostic: levels and kernel launches of the most recent crt_build_bvh on the session's first device (its own launches, before the
  * re-layout for rendering): the build is launch-bound, bench.py reports both in `bvh_build`. */
 int crt_debug_build_stats(uint32_t* levels, uint32_t* launches);
+/* Diagnostic: the host-built instance tree (the sphere tree scenes with more than 64 instances find their candidates in). An instance upload refits
+ * it -- same partition, node spheres recomputed bottom-up, bit for bit what a rebuild with that partition gives -- while the set of cullable
+ * instances is the one it was built for; a median-split build follows when the set changed, when the inner radii have grown by a quarter, or
+ * after 256 refits. *builds = builds of this session so far, *refitsSinceBuild, *nodes = nodes of the current tree. */
+int crt_debug_tlas_stats(uint64_t* builds, uint32_t* refitsSinceBuild, uint32_t* nodes);
 
 #ifdef __cplusplus
 }
