@@ -184,8 +184,8 @@ def run(ctx):
                         mi[tl] = measure_view(sm, flags, 30, f"tiny's two meshes instanced 401 times on a grid, {width}x{height}, " + ("instance tree" if tl == "1" else "linear sphere loop"))
                         if tl == "1":
                             # ... and all 401 MOVING: upstream's Engine_Tick -> SetMeshPosition -> dirty range -> clEnqueueWriteBuffer (Renderer.cpp:268-298,312-320)
-                            # = crt_upload_instances before every frame. An upload is host-only (memcpy + rebuild_instance_master: bounding spheres, cull
-                            # ranges, the median-split instance tree); the frame's slot copies the new tables on its own stream.
+                            # = crt_upload_instances before every frame. An upload is host-only (memcpy + rebuild_instance_master: the uploaded records'
+                            # bounding spheres and cull ranges, a refit of the instance tree); the frame's slot refreshes its tables in one launch on its own stream.
                             inst_m = sm.arenas()["instances"].copy()
                             a_m, iv_m, ip_m = sm.trace_args()
                             q_m = (C.byref(a_m), iv_m.ctypes.data_as(fp), ip_m.ctypes.data_as(fp))
