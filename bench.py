@@ -682,6 +682,8 @@ def main():
     s.close()
     if dist is not None:
         dist.barrier(group=ctl)
+        if node_barrier is not None:
+            node_barrier.close()              # (the creating rank unlinks the shared-memory object)
         dist.destroy_process_group()
 
 

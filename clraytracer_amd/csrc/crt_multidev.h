@@ -84,6 +84,7 @@ struct Group {
     unsigned seq = 0;                           // frame-slot rotation of the session (crt_render)
     bool broken = false;                        // a resize failed on some device and could not be rolled back
     int injectFailure = -1;                     // crt_debug_inject_failure
+    int pack8W = 0, pack8H = 0;                 // frame size every device's byte frames (RGBA8 gather) were last allocated for
     unsigned long long lastGatherBytes = 0; int lastGatherBpp = 0;   // crt_debug_last_gather: what the secondaries copied into the primary for the last frame
 } M;
 
@@ -108,7 +109,7 @@ static void destroy_group()
         release_all();
         delete M.dev[d]; M.dev[d] = nullptr;
     }
-    G = nullptr; M.n = 0; M.seq = 0; M.broken = false; M.injectFailure = -1; M.lastGatherBytes = 0; M.lastGatherBpp = 0;
+    G = nullptr; M.n = 0; M.seq = 0; M.broken = false; M.injectFailure = -1; M.lastGatherBytes = 0; M.lastGatherBpp = 0; M.pack8W = M.pack8H = 0;
     for (int& p : M.peer) p = 0;
 }
 

@@ -247,7 +247,14 @@ int crt_render(const CrtTraceArgs* args, const float invView[16], const float in
     // RGBA8 frames travel as bytes (frame_gathers_rgba8): every device's byte frames exist before a secondary copies into the primary's
     bool gather8 = false;
     { Use u(0); gather8 = frame_gathers_rgba8(flags); }
-    if (gather8) for (int d = 0; d < M.n; ++d) { Use u(d); RCCHK(crt1_prepare_gather8()); }
+    if (gather8) {
+        int w, h;
+        { Use u(0); w = g.width; h = g.height; }
+        if (M.pack8W != w || M.pack8H != h) {                   // once per frame size, not per frame (16 hipSetDevice calls at 8 devices otherwise)
+            for (int d = 0; d < M.n; ++d) { Use u(d); RCCHK(crt1_prepare_gather8()); }
+            M.pack8W = w; M.pack8H = h;
+        }
+    }
     {   // what the secondaries send into the primary for this frame (crt_debug_last_gather)
         Use u(0);
         unsigned long long rows = 0;
