@@ -205,6 +205,29 @@ def test_node_barrier_between_two_ranks(tmp_path):
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("crt_bench_")]      # the creating rank unlinked the object
 
 
+def _node_barrier_other_hosts_worker(rank, world, port, outdir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clraytracer_amd import node_barrier
+        node_barrier._host_id = lambda: f"host-{rank}"              # as if every rank ran on another machine
+        nb = node_barrier.NodeBarrier.create(dist, timeout_ms=5000)
+        open(os.path.join(outdir, f"nb{rank}.txt"), "w").write("none" if nb is None else "made")
+        dist.barrier()                                               # what bench.py keeps using then
+    finally:
+        dist.destroy_process_group()
+
+
+def test_node_barrier_is_not_made_across_hosts(tmp_path):
+    """Ranks that do not share a host (or a /dev/shm) must ALL fall back to torch.distributed's barrier: a mixed group would deadlock."""
+    world = 2
+    port = 29400 + (os.getpid() % 500)
+    mp.spawn(_node_barrier_other_hosts_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert [open(tmp_path / f"nb{r}.txt").read() for r in range(world)] == ["none", "none"]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("crt_bench_")]
+
+
 def test_node_barrier_times_out_instead_of_hanging():
     """Every wait has a deadline: a rank that died cannot hang the others (the barrier returns -1 and the caller gives up loudly)."""
     sys.path.insert(0, ROOT)
