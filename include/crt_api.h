@@ -141,9 +141,9 @@ int crt_download_bvh_roots(uint32_t* dst, size_t firstMesh, size_t count);
 /* Renderer.cpp:337-367: RayGen + Trace (+ PostProcess) for one frame, then (unless ASYNC) wait.
  * invView / invProj are the camera's inverse matrices, row-major (hazard H10: taken as inputs).
  * Frames in flight (no reference counterpart): consecutive CRT_RENDER_ASYNC frames rotate over three frame
- * slots (CRT_FRAMES_IN_FLIGHT=1..8 in the environment, default 3; more than four also wants GPU_MAX_HW_QUEUES=8, which
- * crt_init_devices / crt_init_gpus set before their first HIP call -- effective only if nothing in the process has started the
- * HIP runtime before; otherwise export it yourself), each with its own HIP stream, output buffer and
+ * slots (CRT_FRAMES_IN_FLIGHT=1..8 in the environment, default 3; every slot's stream wants a hardware queue of its own, so
+ * crt_init / crt_init_devices / crt_init_gpus set GPU_MAX_HW_QUEUES=8 before their first HIP call unless it is set -- effective only if
+ * nothing in the process has started the HIP runtime before; otherwise export it yourself), each with its own HIP stream, output buffer and
  * launch lists, so frames run concurrently and the long-ray tail of one is hidden behind the others; the call
  * blocks only to keep at most two frames queued per slot. Mesh / texture / material uploads, resize, queries and reads
  * wait for every frame in flight first; instance uploads do not need to (see crt_upload_instances). Either way scene
