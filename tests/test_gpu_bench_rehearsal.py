@@ -68,7 +68,10 @@ def test_ranks_under_torch_distributed_run(ranks):
                    "--master-port", str(29571 + ranks), "bench.py", "--gpus", str(ranks), "--steps", "6", "--warmup", "2", "--prewarm-ms", "5"])
     check_common(d, ranks)
     assert d["config"]["control_plane"] == "gloo"                           # the rehearsal never uses RCCL (all ranks sit on GPU 0)
-    assert d["config"]["barrier"].startswith("shared-memory node barrier")  # the timed regions are bracketed in shared memory, not over TCP
+    # the timed regions are bracketed in shared memory, not over TCP -- wherever the ranks can share a POSIX shm object (every box so far); the line says which
+    assert d["config"]["barrier"].startswith(("shared-memory node barrier", "torch.distributed barrier"))
+    if os.access("/dev/shm", os.W_OK):
+        assert d["config"]["barrier"].startswith("shared-memory node barrier")
     assert "same region shape" in d["single_gpu_same_workload"]["note"] and d["speedup_vs_single_gpu_same_workload"] > 0
     assert d["delivered_to_host"]["value"] > 0 and d["delivered_to_host_rgba8"]["value"] > 0
     assert f"16-row bands round-robin over {ranks} rank(s)" in d["config"]["tiling"]
